@@ -1,0 +1,170 @@
+/* libipdm_hip.so -- C ABI of the MI355X-native IPDM partial-diffusion sampling hot path.
+ *
+ * The reference (LFY1998/IPDM-PyTorch) is pure Python on this path: its "FFI" is numba's
+ * @jit/@cuda.jit for the FBP convertor and the guidance kernel, and torch.nn for the UNet.  Each
+ * entry point below names the reference interface (file:line under /root/reference) it replaces;
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every `d_*` pointer is a DEVICE pointer owned by the caller
+ *     (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void*.
+ *   - handles (plans / schedules / nets) are owned by the library; distinct handles may be used
+ *     from different threads, one handle may not.
+ *   - every call is asynchronous on `stream`; no call allocates or synchronises except *_create /
+ *     *_destroy (so a caller may capture calls into a hipGraph).
+ *   - return value: 0 = IPDM_OK, negative = error (ipdm_last_error() gives the text); nothing
+ *     throws across the ABI.
+ */
+#ifndef IPDM_HIP_H
+#define IPDM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPDM_OK 0
+#define IPDM_ERR_INVALID (-1)
+#define IPDM_ERR_HIP (-2)
+#define IPDM_ERR_WORKSPACE (-3)
+#define IPDM_ERR_UNSUPPORTED (-4)
+
+const char *ipdm_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int ipdm_abi_version(void);
+
+/* ------------------------------------------------------------------ FBP domain convertor ---- */
+/* Geometry of Recon/FBP_kernel.py:28-67 (FBP.__init__); the defaults of the reference are
+ * n_views=2000 n_det=912 grid_n=512 da=0.0010125 det_offset=3.75 dtheta_deg=0.18
+ * source_origin=59.5 fov_half=21. */
+typedef struct ipdm_fbp_geom {
+    int32_t n_views, n_det, grid_n;
+    double da, det_offset, dtheta_deg, source_origin, fov_half;
+} ipdm_fbp_geom;
+typedef struct ipdm_fbp_plan ipdm_fbp_plan;
+
+/* replaces FBP.__init__ + getrphi (Recon/FBP_kernel.py:28-84): builds theta/phi/r (float64),
+ * nda/h_RL/cos weights (float32) on the host and uploads them. */
+int ipdm_fbp_plan_create(const ipdm_fbp_geom *geom, ipdm_fbp_plan **out);
+int ipdm_fbp_plan_destroy(ipdm_fbp_plan *plan);
+/* bytes of scratch ipdm_fbp_forward needs for a batch of B sinograms (the filtered sinogram). */
+size_t ipdm_fbp_workspace_bytes(const ipdm_fbp_plan *plan, int32_t B);
+/* replaces FBP.convert (Recon/FBP_kernel.py:86-122) = flip + cos weight + dtheta + conv_pj /
+ * conv_kernel (:125-143) + fbp_cpu / fbp_kernel (:146-184) + flip.  d_sino [B,n_views,n_det] f32,
+ * d_img [B,grid_n,grid_n] f32 (overwritten).  `gain` multiplies the sinogram first (the G of
+ * Utils/train_test_utils.py:455-458,476). */
+int ipdm_fbp_forward(ipdm_fbp_plan *plan, const float *d_sino, float *d_img, int32_t B, int32_t flip,
+                     float gain, void *d_ws, size_t ws_bytes, void *stream);
+/* the two halves separately (parity tests): weighted+ramp-filtered sinogram, and back-projection of
+ * an already filtered sinogram (no flips). */
+int ipdm_fbp_filter(ipdm_fbp_plan *plan, const float *d_sino, float *d_filtered, int32_t B, int32_t flip,
+                    float gain, void *stream);
+int ipdm_fbp_backproject(ipdm_fbp_plan *plan, const float *d_filtered, float *d_img, int32_t B,
+                         int32_t flip, void *stream);
+/* detector coordinate u(t,p) = (alpha - nda[0])/da + 0.5 (float64) of the listed flat pixel indices,
+ * d_u [n_views, npix]: the "FBP index map" (Recon/FBP_kernel.py:176-178). */
+int ipdm_fbp_index_map(ipdm_fbp_plan *plan, const int32_t *d_pix, int32_t npix, double *d_u, void *stream);
+/* host copies of the geometry tables, for parity tests against the reference's FBP.__init__:
+ * which = 0 theta[n_views] f64, 1 phi[grid_n^2] f64, 2 r[grid_n^2] f64, 3 nda[n_det] f32,
+ * 4 h_RL[2*n_det-1] f32, 5 weight[n_det] f32.  Returns the element count, or <0. */
+int64_t ipdm_fbp_table(const ipdm_fbp_plan *plan, int32_t which, void *host_out, int64_t cap_elems);
+/* replaces tensor_sharpen (Utils/train_test_utils.py:868-878), per slice, zero padding. */
+int ipdm_sharpen3x3(const float *d_in, float *d_out, int32_t B, int32_t H, int32_t W, float n, void *stream);
+
+/* ------------------------------------------------------------------ diffusion schedule ------ */
+typedef struct ipdm_schedule ipdm_schedule;
+/* replaces cosine_beta_schedule + GaussianDiffusion.__init__ (Model/model.py:366-421), float64. */
+int ipdm_schedule_create(int32_t timesteps, double schedule_power, ipdm_schedule **out);
+int ipdm_schedule_destroy(ipdm_schedule *s);
+/* replaces _extract (Model/model.py:424-428) for the 8 tables the path uses; out[0..7] =
+ * sqrt_ac, sqrt_1m_ac, sqrt_recip_ac, sqrt_recipm1_ac, post_mean_coef1, post_mean_coef2,
+ * post_log_var_clipped, post_var, each gathered at t and cast to float32. */
+int ipdm_schedule_coeffs(const ipdm_schedule *s, int32_t t, float out[8]);
+/* cosine_beta_schedule(ts, schedule_power=power)[i] (Model/model.py:546,552), float64. */
+int ipdm_cosine_lambda(int32_t ts, double power, int32_t i, double *out);
+
+/* ------------------------------------------------------------------ DDPM elementwise -------- */
+/* counter-based N(0,1) generator (Philox4x32-10 + Box-Muller) replacing torch.randn_like
+ * (Model/model.py:440,509).  Element e of slice b of draw `draw` depends only on
+ * (seed, slice_id0+b, draw, e): results are invariant to how slices are sharded over GPUs. */
+int ipdm_randn(float *d_out, int32_t B, int64_t n_per_slice, uint64_t seed, int64_t slice_id0,
+               int64_t draw, void *stream);
+/* replaces q_sample (Model/model.py:438-445): out = sa*x + s1m*noise. */
+int ipdm_q_sample(const ipdm_schedule *s, int32_t t, const float *d_x, const float *d_noise, float *d_out,
+                  int64_t n, void *stream);
+size_t ipdm_ddpm_workspace_bytes(int32_t B);
+/* replaces p_mean_variance_condition + p_sample_condition (Model/model.py:492-515) with per-slice
+ * statistics.  All tensors [B, n_per_slice].  Guidance lambda: scalar `lambda_scalar` when
+ * d_lambda_map == NULL, else the small map d_lambda_map [B, mh, mw] nearest-upsampled to [H, W]
+ * (F.interpolate rule, Model/model.py:559-560); then n_per_slice must equal H*W. */
+int ipdm_ddpm_step(const ipdm_schedule *s, int32_t t, const float *d_eps_pred, const float *d_x_t,
+                   const float *d_x0, const float *d_noise, float *d_out, int32_t B, int32_t H, int32_t W,
+                   double lambda_scalar, const float *d_lambda_map, int32_t mh, int32_t mw,
+                   int32_t clip_denoised, void *d_ws, size_t ws_bytes, void *stream);
+/* elementwise helpers of guided_reverse_process: out = clamp(x) (mode 0: [0,1], 1: min 0)
+ * (Model/model.py:569-573); out = a*x + b*y + c*z (guide update :625-635; z may be NULL);
+ * out = 0.5*(x+y) (:637-638). */
+int ipdm_clamp(const float *d_x, float *d_out, int64_t n, int32_t mode, void *stream);
+int ipdm_axpbypcz(const float *d_x, const float *d_y, const float *d_z, float *d_out, int64_t n,
+                  double a, double b, double c, void *stream);
+/* guidance map after pass 0 (Model/model.py:575-580 img / :596-600,614 proj) + weight_lambda curve
+ * (Utils/train_test_utils.py:831-865).  mode 0 = img, 1 = proj.  d_x, d_img [B,H,W];
+ * d_Lambda [B, H/k, W/k] f32 (the curve output the lambda kernel exponentiates with);
+ * d_expmax [B] f32 = max of exp(amplitude*delta) per slice (adaptive branch, :602-613). */
+size_t ipdm_guidance_workspace_bytes(int32_t B, int32_t H, int32_t W);
+int ipdm_guidance_map(const float *d_x, const float *d_img, float *d_Lambda, float *d_expmax, int32_t B,
+                      int32_t H, int32_t W, int32_t kernel, double amplitude, int32_t mode,
+                      const double *p1, const double *p2, void *d_ws, size_t ws_bytes, void *stream);
+/* replaces condition_lambda_ratio_cuda (Model/model.py:328-351) + np.clip(.,0.05,0.99) (:558):
+ * d_out[B,mh,mw] f32 from d_Lambda for inner step i of a pass of ts steps. */
+int ipdm_lambda_ratio(const float *d_Lambda, float *d_out, int64_t n, int32_t i, int32_t ts, void *stream);
+/* torch.median over each slice (lower median), for tests of the selection kernel. */
+int ipdm_slice_median(const float *d_x, float *d_med, int32_t B, int64_t n_per_slice, void *d_ws,
+                      size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------ UNet denoiser ----------- */
+/* UNetModel.__init__ arguments (Model/model.py:191-203). */
+typedef struct ipdm_unet_cfg {
+    int32_t in_channels, model_channels, out_channels, num_res_blocks, num_heads;
+    int32_t n_mult, n_attn;
+    double channel_mult[16];
+    int32_t attention_resolutions[16];
+} ipdm_unet_cfg;
+typedef struct ipdm_unet ipdm_unet;
+
+/* parameter inventory in the reference's state_dict key layout (Utils/loggerx.py:62-80 checkpoints):
+ * name e.g. "down_blocks.1.0.conv1.2.weight"; shape padded with 1s to 4 dims. */
+int ipdm_unet_param_count(const ipdm_unet_cfg *cfg);
+int ipdm_unet_param_info(const ipdm_unet_cfg *cfg, int32_t idx, char *name, int32_t name_cap,
+                         int32_t shape[4], int32_t *ndim);
+/* replaces UNetModel.__init__ + load_state_dict: `weights[i]` is a HOST pointer to parameter i
+ * (float32, contiguous, reference layout); the library repacks them into its own device layout. */
+int ipdm_unet_create(const ipdm_unet_cfg *cfg, const float *const *weights, int32_t n_weights,
+                     ipdm_unet **out);
+int ipdm_unet_destroy(ipdm_unet *net);
+size_t ipdm_unet_workspace_bytes(ipdm_unet *net, int32_t B, int32_t H, int32_t W);
+/* replaces UNetModel.forward (Model/model.py:283-310) for one integer timestep shared by the batch
+ * (the sampler's torch.full((1,), i), :564).  d_x [B,in_ch,H,W] -> d_eps [B,out_ch,H,W]. */
+int ipdm_unet_forward(ipdm_unet *net, const float *d_x, int32_t t, float *d_eps, int32_t B, int32_t H,
+                      int32_t W, void *d_ws, size_t ws_bytes, void *stream);
+
+/* op-level entry points (parity tests of the individual kernels against torch-CPU ops) */
+/* F.conv2d(cat(x1,x2) [upsampled to H,W by nearest], w, b, stride, padding=k/2) with optional fused
+ * GroupNorm(+SiLU) prologue over the concatenated input and optional residual add.
+ *   d_x1 [B,C1,Hs,Ws], d_x2 [B,C2,Hs,Ws] or NULL; source size (Hs,Ws) != (H,W) => nearest upsample
+ *   (Model/model.py:168); w_host [Cout,C1+C2,k,k] HOST pointer in reference layout; act: 0 none,
+ *   1 GN only, 2 GN+SiLU; d_res [B,Cout,Ho,Wo] or NULL. */
+int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, int32_t C2, int32_t B, int32_t Hs,
+                   int32_t Ws, int32_t H, int32_t W, const float *w_host, const float *b_host, int32_t Cout,
+                   int32_t ksize, int32_t stride, int32_t act, int32_t groups, const float *gamma_host,
+                   const float *beta_host, const float *d_res, float *d_out, void *stream);
+/* AttentionBlock core (Model/model.py:148-153): d_qkv [B, heads*3*d, T] (per-head (q,k,v) chunks)
+ * -> d_out [B, heads*d, T]. */
+int ipdm_op_attention(const float *d_qkv, float *d_out, int32_t B, int32_t heads, int32_t d, int32_t T,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPDM_HIP_H */

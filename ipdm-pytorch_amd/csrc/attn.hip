@@ -1,0 +1,159 @@
+// Self-attention core of AttentionBlock (Model/model.py:148-153) for gfx950: flash-style, scores
+// never leave registers/LDS (the reference materialises a T x T score tensor: 268-812 MB per
+// sample and block), exact-f32 MFMA for both contractions.
+//
+//   qkv [B, heads*3*d, T] with per-head (q,k,v) chunks (the reshape/chunk of :148), d = 64
+//   S[s,t]  = sum_c (k[c,s]*scale) * (q[c,t]*scale),  scale = d^(-1/4)            (:149-150)
+//   P       = softmax over keys s                                                     (:151)
+//   out[c,t]= sum_s v[c,s] * P[s,t]                                                   (:152)
+//
+// Mapping: a workgroup = 4 waves = 128 queries of one (sample, head); each wave owns 32 queries.
+// QK^T is computed "swapped" (keys on the MFMA row index, queries on the lane) so that
+//   * a lane holds 16 of the 32 scores of ITS query per key block -> row max / row sum are 16
+//     in-register ops + one cross-half shuffle;
+//   * the score accumulator registers are directly the B operand (k-pair = keys crow(r,0),crow(r,1))
+//     of the P.V MFMA, with V read from LDS as the A operand -- no data movement for P at all;
+//   * the output accumulator has the query on the lane too, so the online-softmax rescale is a
+//     per-lane multiply and the final store is coalesced along t.
+// K/V tiles of 64 keys x 64 channels are staged in LDS ([c][s] for K; [c][s] with an odd pitch
+// for V so that the 32 channel rows of one key hit 32 different banks).
+#include "unet_kernels.h"
+
+using namespace ipdm;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int D = 64;          // head dim (C/heads); the reference configs all have 256/4
+constexpr int KV = 64;         // keys per LDS tile
+constexpr int KP = KV;         // K pitch  [c][s]
+constexpr int VP = KV + 1;     // V pitch  [c][s], odd -> conflict-free column reads
+
+__device__ inline int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restrict__ qkv, float *__restrict__ out,
+                                                           int heads, int T, float scale)
+{
+    __shared__ float k_lds[D * KP];
+    __shared__ float v_lds[D * VP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int bh = blockIdx.y;                      // sample*heads + head
+    const int b = bh / heads, head = bh % heads;
+    const float *qp = qkv + ((size_t)b * heads * 3 * D + (size_t)head * 3 * D) * T;
+    const float *kp = qp + (size_t)D * T;
+    const float *vp = qp + (size_t)2 * D * T;
+    const int t0 = blockIdx.x * 128 + wave * 32;
+    const int t = t0 + l31;
+    const bool tvalid = t < T;
+
+    // Q as the B operand of S = K^T Q: k-pair p covers channels (2p, 2p+1); lane holds q[2p+lh][t]*scale
+    float qreg[D / 2];
+#pragma unroll
+    for (int p = 0; p < D / 2; ++p) qreg[p] = tvalid ? qp[(size_t)(2 * p + lh) * T + t] * scale : 0.0f;
+
+    f32x16 o[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cb][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    for (int s0 = 0; s0 < T; s0 += KV) {
+        __syncthreads();   // previous tile fully consumed
+        // stage K (scaled) and V: 64 channels x 64 keys each, coalesced along keys
+#pragma unroll
+        for (int e = 0; e < (D * KV) / 256; ++e) {
+            const int idx = tid + e * 256;
+            const int c = idx / KV, s = idx % KV;
+            const bool ok = (s0 + s) < T;
+            k_lds[c * KP + s] = ok ? kp[(size_t)c * T + s0 + s] * scale : 0.0f;
+            v_lds[c * VP + s] = ok ? vp[(size_t)c * T + s0 + s] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sb = 0; sb < KV / 32; ++sb) {
+            if (s0 + sb * 32 >= T) break;          // wave-uniform
+            // ---- S[s, t] for 32 keys x 32 queries (K dim = 64 channels = 32 k-pairs)
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+            for (int p = 0; p < D / 2; ++p) {
+                const float av = k_lds[(2 * p + lh) * KP + sb * 32 + l31];   // A[i=key][k=channel]
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qreg[p], sacc, 0, 0, 0);
+            }
+            // ---- online softmax over keys (rows), per query (lane & 31)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int s = s0 + sb * 32 + crow(r, lh);
+                if (s >= T) sacc[r] = -INFINITY;
+                mx = fmaxf(mx, sacc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = expf(m_run - m_new);          // m_run = -inf on the first block -> 0
+            float rs = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = expf(sacc[r] - m_new);
+                rs += sacc[r];
+            }
+            rs += __shfl_xor(rs, 32, 64);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+            // ---- O[c, t] += sum_s V[c, s] P[s, t]; accumulator register r of P is the k-pair
+            //      (s = crow(r,0) for lanes 0-31, crow(r,1) for lanes 32-63)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int s = sb * 32 + crow(r, lh);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const float av = v_lds[(cb * 32 + l31) * VP + s];      // A[i=channel][k=key]
+                    o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sacc[r], o[cb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (tvalid) {
+        const float inv = 1.0f / l_run;
+        float *op = out + ((size_t)b * heads * D + (size_t)head * D) * T;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cb * 32 + crow(r, lh);
+                op[(size_t)c * T + t] = o[cb][r] * inv;
+            }
+    }
+}
+
+}  // namespace
+
+namespace ipdm {
+
+int attention_launch(const float *qkv, float *out, int B, int heads, int d, int T, hipStream_t st)
+{
+    IPDM_REQUIRE(qkv && out && B > 0 && heads > 0 && T > 0, "attention: bad argument");
+    if (d != D) { set_error("attention: head dim %d unsupported (kernel is specialised for %d)", d, D); return IPDM_ERR_UNSUPPORTED; }
+    // scale = 1/sqrt(sqrt(C/heads)) (Model/model.py:149); python double -> f32 scalar
+    const float scale = (float)(1.0 / sqrt(sqrt((double)d)));
+    dim3 grid(cdiv(T, 128), B * heads);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, heads, T, scale);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+}  // namespace ipdm
+
+extern "C" int ipdm_op_attention(const float *d_qkv, float *d_out, int32_t B, int32_t heads, int32_t d, int32_t T,
+                                 void *stream)
+{
+    return ipdm::attention_launch(d_qkv, d_out, B, heads, d, T, (hipStream_t)stream);
+}

@@ -1,0 +1,642 @@
+// Diffusion arithmetic of the guided partial-diffusion sampler for gfx950: schedule tables,
+// counter-based noise, q_sample, the fused guided reverse step with per-slice whitening statistics,
+// guidance maps (abs-diff / median / avg-pool / exp / polynomial curve) and the per-step lambda map.
+//
+// Replaces (reference file:line): cosine_beta_schedule + GaussianDiffusion.__init__
+// (Model/model.py:366-421), q_sample (:438-445), p_mean_variance_condition + p_sample_condition
+// (:492-515), the post-pass guidance-map code of guided_reverse_process (:574-614),
+// condition_lambda_ratio_cuda (:328-351) and weight_lambda (Utils/train_test_utils.py:831-865).
+// Every reduction is per slice, done with a fixed block decomposition and fp64
+// partial sums combined in a fixed order: deterministic and independent of batch sharding.
+#include <cmath>
+#include <vector>
+#include "common.h"
+
+using namespace ipdm;
+
+// =============================================================================== schedule
+struct ipdm_schedule {
+    int T;
+    std::vector<double> sqrt_ac, sqrt_1m_ac, sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, logvar, var;
+};
+
+static void cosine_betas(int T, double power, std::vector<double> &betas)
+{
+    const double s = 0.008, pi = 3.141592653589793;
+    std::vector<double> ac(T + 1);
+    for (int i = 0; i <= T; ++i) {
+        double x = (double)i;
+        double c = cos(((x / T) + s) / (1 + s) * pi * 0.5);
+        ac[i] = pow(c * c, power);
+    }
+    double a0 = ac[0];
+    for (int i = 0; i <= T; ++i) ac[i] = ac[i] / a0;
+    betas.resize(T);
+    for (int i = 0; i < T; ++i) {
+        double b = 1 - (ac[i + 1] / ac[i]);
+        betas[i] = b < 0 ? 0 : (b > 0.999 ? 0.999 : b);
+    }
+}
+
+extern "C" int ipdm_schedule_create(int32_t T, double power, ipdm_schedule **out)
+{
+    IPDM_REQUIRE(T > 0 && out, "schedule_create: bad argument");
+    ipdm_schedule *s = new ipdm_schedule();
+    s->T = T;
+    std::vector<double> b;
+    cosine_betas(T, power, b);
+    std::vector<double> a(T), ac(T), acp(T);
+    double prod = 1.0;
+    for (int i = 0; i < T; ++i) {
+        a[i] = 1.0 - b[i];
+        prod *= a[i];
+        ac[i] = prod;
+        acp[i] = i == 0 ? 1.0 : ac[i - 1];
+    }
+    s->sqrt_ac.resize(T); s->sqrt_1m_ac.resize(T); s->sqrt_recip_ac.resize(T); s->sqrt_recipm1_ac.resize(T);
+    s->coef1.resize(T); s->coef2.resize(T); s->logvar.resize(T); s->var.resize(T);
+    for (int i = 0; i < T; ++i) {
+        s->sqrt_ac[i] = sqrt(ac[i]);
+        s->sqrt_1m_ac[i] = sqrt(1.0 - ac[i]);
+        s->sqrt_recip_ac[i] = sqrt(1.0 / ac[i]);
+        s->sqrt_recipm1_ac[i] = sqrt(1.0 / ac[i] - 1);
+        s->var[i] = b[i] * (1.0 - acp[i]) / (1.0 - ac[i]);
+        s->logvar[i] = log(s->var[i] < 1e-20 ? 1e-20 : s->var[i]);
+        s->coef1[i] = b[i] * sqrt(acp[i]) / (1.0 - ac[i]);
+        s->coef2[i] = (1.0 - acp[i]) * sqrt(a[i]) / (1.0 - ac[i]);
+    }
+    *out = s;
+    return IPDM_OK;
+}
+
+extern "C" int ipdm_schedule_destroy(ipdm_schedule *s) { delete s; return IPDM_OK; }
+
+extern "C" int ipdm_schedule_coeffs(const ipdm_schedule *s, int32_t t, float out[8])
+{
+    IPDM_REQUIRE(s && out && t >= 0 && t < s->T, "schedule_coeffs: t=%d out of range", t);
+    out[0] = (float)s->sqrt_ac[t];
+    out[1] = (float)s->sqrt_1m_ac[t];
+    out[2] = (float)s->sqrt_recip_ac[t];
+    out[3] = (float)s->sqrt_recipm1_ac[t];
+    out[4] = (float)s->coef1[t];
+    out[5] = (float)s->coef2[t];
+    out[6] = (float)s->logvar[t];
+    out[7] = (float)s->var[t];
+    return IPDM_OK;
+}
+
+extern "C" int ipdm_cosine_lambda(int32_t ts, double power, int32_t i, double *out)
+{
+    IPDM_REQUIRE(ts > 0 && i >= 0 && i < ts && out, "cosine_lambda: bad argument");
+    std::vector<double> b;
+    cosine_betas(ts, power, b);
+    *out = b[i];
+    return IPDM_OK;
+}
+
+// =============================================================================== noise
+__device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// counter = (element/4 lo32, element/4 hi32 | draw << 8 .., slice lo, slice hi ^ draw hi): see host note.
+__global__ void __launch_bounds__(256) randn_kernel(float *__restrict__ out, long n, uint32_t seed_lo,
+                                                    uint32_t seed_hi, long slice_id0, long draw)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;   // quad index inside the slice
+    const long nq = (n + 3) / 4;
+    if (q >= nq) return;
+    const long slice = slice_id0 + blockIdx.y;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)draw, (uint32_t)slice, (uint32_t)((uint64_t)slice >> 32) ^ ((uint32_t)((uint64_t)q >> 32) << 16) ^ (uint32_t)((uint64_t)draw >> 32)};
+    philox4x32_10(c, seed_lo, seed_hi);
+    float z[4];
+    const float two_pi = 6.283185307179586f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(two_pi * u2, &sn, &cs);
+        z[2 * h] = rad * cs;
+        z[2 * h + 1] = rad * sn;
+    }
+    float *dst = out + (size_t)blockIdx.y * n + q * 4;
+    if (q * 4 + 3 < n && ((n & 3) == 0)) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(z[0], z[1], z[2], z[3]);
+    } else {
+        for (int e = 0; e < 4; ++e)
+            if (q * 4 + e < n) dst[e] = z[e];
+    }
+}
+
+extern "C" int ipdm_randn(float *d_out, int32_t B, int64_t n, uint64_t seed, int64_t slice_id0, int64_t draw,
+                          void *stream)
+{
+    IPDM_REQUIRE(d_out && B > 0 && n > 0, "randn: bad argument");
+    dim3 grid(cdiv((n + 3) / 4, 256), B);
+    hipLaunchKernelGGL(randn_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_out, (long)n, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), (long)slice_id0, (long)draw);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+// =============================================================================== elementwise
+__global__ void __launch_bounds__(256) q_sample_kernel(const float *__restrict__ x, const float *__restrict__ nz,
+                                                       float *__restrict__ out, long n, float sa, float s1m)
+{
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += stride) {
+        float4 a = *reinterpret_cast<const float4 *>(x + i);
+        float4 b = *reinterpret_cast<const float4 *>(nz + i);
+        float4 o = make_float4(sa * a.x + s1m * b.x, sa * a.y + s1m * b.y, sa * a.z + s1m * b.z, sa * a.w + s1m * b.w);
+        *reinterpret_cast<float4 *>(out + i) = o;
+    }
+    if (i < n && i + 3 >= n)
+        for (long e = i; e < n; ++e) out[e] = sa * x[e] + s1m * nz[e];
+}
+
+static inline int ew_grid(long n) { int g = cdiv(n, 1024); return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
+
+extern "C" int ipdm_q_sample(const ipdm_schedule *s, int32_t t, const float *d_x, const float *d_noise, float *d_out,
+                             int64_t n, void *stream)
+{
+    IPDM_REQUIRE(s && d_x && d_noise && d_out && n > 0 && (n % 4) == 0, "q_sample: bad argument (n %% 4 != 0?)");
+    float c[8];
+    int rc = ipdm_schedule_coeffs(s, t, c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, d_x, d_noise, d_out,
+                       (long)n, c[0], c[1]);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+__global__ void __launch_bounds__(256) clamp_kernel(const float *__restrict__ x, float *__restrict__ out, long n, int mode)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        float v = x[i];
+        v = fmaxf(v, 0.0f);
+        if (mode == 0) v = fminf(v, 1.0f);
+        out[i] = v;
+    }
+}
+
+extern "C" int ipdm_clamp(const float *d_x, float *d_out, int64_t n, int32_t mode, void *stream)
+{
+    IPDM_REQUIRE(d_x && d_out && n > 0, "clamp: bad argument");
+    hipLaunchKernelGGL(clamp_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, d_x, d_out, (long)n, mode);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+__global__ void __launch_bounds__(256) axpbypcz_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                       const float *__restrict__ z, float *__restrict__ out, long n,
+                                                       float a, float b, float c)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        float v = a * x[i] + b * y[i];
+        if (z) v = v + c * z[i];
+        out[i] = v;
+    }
+}
+
+extern "C" int ipdm_axpbypcz(const float *d_x, const float *d_y, const float *d_z, float *d_out, int64_t n, double a,
+                             double b, double c, void *stream)
+{
+    IPDM_REQUIRE(d_x && d_y && d_out && n > 0, "axpbypcz: bad argument");
+    hipLaunchKernelGGL(axpbypcz_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_z, d_out,
+                       (long)n, (float)a, (float)b, (float)c);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+// =============================================================================== guided reverse step
+// Per-slice statistics use RED_BLOCKS workgroups per slice; block partials (fp64) land in the
+// workspace and every consumer workgroup re-reduces them in a fixed order.
+constexpr int RED_BLOCKS = 64;
+
+struct StepCoef {
+    float sa, s1m, sr, srm1, c1, c2, sigma;
+    float w_pred, w_cond;   // scalar guidance
+    int use_map, H, W, mh, mw, clip;
+    float sy, sx;           // nearest scales (float32, as ATen computes them)
+};
+
+__device__ inline float lambda_at(const StepCoef &k, const float *__restrict__ lmap, long idx)
+{
+    int y = (int)(idx / k.W), x = (int)(idx - (long)y * k.W);
+    int syi = min((int)floorf((float)y * k.sy), k.mh - 1);
+    int sxi = min((int)floorf((float)x * k.sx), k.mw - 1);
+    return lmap[(size_t)syi * k.mw + sxi];
+}
+
+__device__ inline void block_reduce_store(double *vals, int nvals, double *dst)
+{
+    __shared__ double red[4][8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = 0; k < nvals; ++k) {
+        double v = wave_sum(vals[k]);
+        if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nvals) dst[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// sums partials[b][0..RED_BLOCKS)[k] in fixed order -> every thread gets the totals
+__device__ inline void load_totals(const double *__restrict__ partials, int nvals, double *tot)
+{
+    __shared__ double totals[8];
+    if (threadIdx.x < 64) {
+        for (int k = 0; k < nvals; ++k) {
+            double v = (threadIdx.x < RED_BLOCKS) ? partials[threadIdx.x * 8 + k] : 0.0;
+            v = wave_sum(v);
+            if (threadIdx.x == 0) totals[k] = v;
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < nvals; ++k) tot[k] = totals[k];
+    __syncthreads();
+}
+
+__device__ inline void mean_std(double sum, double sumsq, long n, float &mean, float &sd)
+{
+    double m = sum / (double)n;
+    double var = (sumsq - (double)n * m * m) / (double)(n - 1);   // unbiased (torch.std)
+    mean = (float)m;
+    sd = (float)sqrt(var > 0 ? var : 0.0);
+}
+
+// pass A: sums of pred, pred^2, cond, cond^2  (cond = (x_t - sa*x0)/s1m, Model/model.py:447-450)
+__global__ void __launch_bounds__(256) step_stats1_kernel(const float *__restrict__ pred, const float *__restrict__ xt,
+                                                          const float *__restrict__ x0, long n, StepCoef k,
+                                                          double *__restrict__ ws)
+{
+    const int b = blockIdx.y;
+    const size_t off = (size_t)b * n;
+    double v[4] = {0, 0, 0, 0};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)RED_BLOCKS * 256) {
+        float p = pred[off + i];
+        float c = (xt[off + i] - k.sa * x0[off + i]) / k.s1m;
+        v[0] += p; v[1] += (double)p * p; v[2] += c; v[3] += (double)c * c;
+    }
+    block_reduce_store(v, 4, ws + ((size_t)b * 2 * RED_BLOCKS + blockIdx.x) * 8);
+}
+
+// pass B: sums of mixed, mixed^2; mixed = w_pred*whiten(pred) + w_cond*whiten(cond) (:496)
+__global__ void __launch_bounds__(256) step_stats2_kernel(const float *__restrict__ pred, const float *__restrict__ xt,
+                                                          const float *__restrict__ x0, const float *__restrict__ lmap,
+                                                          long n, StepCoef k, double *__restrict__ ws)
+{
+    const int b = blockIdx.y;
+    const size_t off = (size_t)b * n;
+    double t[4];
+    load_totals(ws + (size_t)b * 2 * RED_BLOCKS * 8, 4, t);
+    float m1, s1, m2, s2;
+    mean_std(t[0], t[1], n, m1, s1);
+    mean_std(t[2], t[3], n, m2, s2);
+    const float *lm = k.use_map ? lmap + (size_t)b * k.mh * k.mw : nullptr;
+    double v[2] = {0, 0};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)RED_BLOCKS * 256) {
+        float p = (pred[off + i] - m1) / s1;
+        float c = ((xt[off + i] - k.sa * x0[off + i]) / k.s1m - m2) / s2;
+        float wp = k.w_pred, wc = k.w_cond;
+        if (k.use_map) { wc = lambda_at(k, lm, i); wp = 1.0f - wc; }
+        float mix = wp * p + wc * c;
+        v[0] += mix; v[1] += (double)mix * mix;
+    }
+    block_reduce_store(v, 2, ws + ((size_t)b * 2 * RED_BLOCKS + RED_BLOCKS + blockIdx.x) * 8);
+}
+
+// pass C: eps = whiten(mixed); x0_hat; clamp; posterior mean; + sigma*noise (:497-515)
+__global__ void __launch_bounds__(256) step_apply_kernel(const float *__restrict__ pred, const float *__restrict__ xt,
+                                                         const float *__restrict__ x0, const float *__restrict__ noise,
+                                                         const float *__restrict__ lmap, float *__restrict__ out, long n,
+                                                         StepCoef k, const double *__restrict__ ws)
+{
+    const int b = blockIdx.y;
+    const size_t off = (size_t)b * n;
+    double t[4], u[2];
+    load_totals(ws + (size_t)b * 2 * RED_BLOCKS * 8, 4, t);
+    load_totals(ws + ((size_t)b * 2 * RED_BLOCKS + RED_BLOCKS) * 8, 2, u);
+    float m1, s1, m2, s2, m3, s3;
+    mean_std(t[0], t[1], n, m1, s1);
+    mean_std(t[2], t[3], n, m2, s2);
+    mean_std(u[0], u[1], n, m3, s3);
+    const float *lm = k.use_map ? lmap + (size_t)b * k.mh * k.mw : nullptr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float x = xt[off + i];
+        float p = (pred[off + i] - m1) / s1;
+        float c = ((x - k.sa * x0[off + i]) / k.s1m - m2) / s2;
+        float wp = k.w_pred, wc = k.w_cond;
+        if (k.use_map) { wc = lambda_at(k, lm, i); wp = 1.0f - wc; }
+        float eps = ((wp * p + wc * c) - m3) / s3;
+        float xr = k.sr * x - k.srm1 * eps;
+        if (k.clip) xr = fminf(fmaxf(xr, -1.0f), 1.0f);
+        float mean = k.c1 * xr + k.c2 * x;
+        out[off + i] = mean + k.sigma * noise[off + i];
+    }
+}
+
+extern "C" size_t ipdm_ddpm_workspace_bytes(int32_t B)
+{
+    return B <= 0 ? 0 : (size_t)B * 2 * RED_BLOCKS * 8 * sizeof(double);
+}
+
+extern "C" int ipdm_ddpm_step(const ipdm_schedule *s, int32_t t, const float *d_eps_pred, const float *d_x_t,
+                              const float *d_x0, const float *d_noise, float *d_out, int32_t B, int32_t H, int32_t W,
+                              double lambda_scalar, const float *d_lambda_map, int32_t mh, int32_t mw,
+                              int32_t clip_denoised, void *d_ws, size_t ws_bytes, void *stream)
+{
+    IPDM_REQUIRE(s && d_eps_pred && d_x_t && d_x0 && d_noise && d_out && d_ws && B > 0 && H > 0 && W > 0,
+                 "ddpm_step: bad argument");
+    if (ws_bytes < ipdm_ddpm_workspace_bytes(B)) { set_error("ddpm_step: workspace too small"); return IPDM_ERR_WORKSPACE; }
+    float c[8];
+    int rc = ipdm_schedule_coeffs(s, t, c);
+    if (rc) return rc;
+    StepCoef k;
+    k.sa = c[0]; k.s1m = c[1]; k.sr = c[2]; k.srm1 = c[3]; k.c1 = c[4]; k.c2 = c[5];
+    // nonzero_mask * exp(0.5*logvar) (Model/model.py:511-514): f32 arithmetic
+    k.sigma = (t == 0) ? 0.0f : expf(0.5f * c[6]);
+    k.w_pred = (float)(1.0 - lambda_scalar);   // python: (1 - lambda_) in double, then cast (torch scalar rule)
+    k.w_cond = (float)lambda_scalar;
+    k.use_map = d_lambda_map != nullptr;
+    k.H = H; k.W = W; k.mh = mh; k.mw = mw; k.clip = clip_denoised;
+    if (k.use_map) {
+        IPDM_REQUIRE(mh > 0 && mw > 0, "ddpm_step: lambda map without dims");
+        k.sy = (float)mh / (float)H;   // ATen nearest: scale = in/out in float32
+        k.sx = (float)mw / (float)W;
+    } else { k.sy = k.sx = 0.f; }
+    const long n = (long)H * W;
+    hipStream_t st = (hipStream_t)stream;
+    double *ws = (double *)d_ws;
+    hipLaunchKernelGGL(step_stats1_kernel, dim3(RED_BLOCKS, B), dim3(256), 0, st, d_eps_pred, d_x_t, d_x0, n, k, ws);
+    hipLaunchKernelGGL(step_stats2_kernel, dim3(RED_BLOCKS, B), dim3(256), 0, st, d_eps_pred, d_x_t, d_x0, d_lambda_map, n, k, ws);
+    int gx = cdiv(n, 256 * 4); if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(step_apply_kernel, dim3(gx, B), dim3(256), 0, st, d_eps_pred, d_x_t, d_x0, d_noise, d_lambda_map, d_out, n, k, ws);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+// =============================================================================== median (radix select)
+// state per slice: {prefix, k_remaining}; hist per slice: 256 bins.
+__device__ inline uint32_t float_key(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ inline float key_float(uint32_t k)
+{
+    uint32_t b = (k >> 31) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(b);
+}
+
+__global__ void __launch_bounds__(256) select_hist_kernel(const float *__restrict__ x, long n, const uint32_t *__restrict__ state,
+                                                          uint32_t *__restrict__ hist, int shift)
+{
+    __shared__ uint32_t h[256];
+    const int b = blockIdx.y;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t prefix = state[b * 2];
+    const uint32_t mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    const float *src = x + (size_t)b * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        uint32_t k = float_key(src[i]);
+        if ((k & mask) == (prefix & mask)) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[b * 256 + threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256) select_scan_kernel(uint32_t *__restrict__ state, uint32_t *__restrict__ hist, int shift,
+                                                          float *__restrict__ med_out)
+{
+    __shared__ uint32_t h[256];
+    const int b = blockIdx.x;
+    h[threadIdx.x] = hist[b * 256 + threadIdx.x];
+    hist[b * 256 + threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t k = state[b * 2 + 1], cum = 0;
+        int bin = 255;
+        for (int i = 0; i < 256; ++i) {
+            if (cum + h[i] > k) { bin = i; break; }
+            cum += h[i];
+        }
+        uint32_t prefix = state[b * 2] | ((uint32_t)bin << shift);
+        state[b * 2] = prefix;
+        state[b * 2 + 1] = k - cum;
+        if (shift == 0 && med_out) med_out[b] = key_float(prefix);
+    }
+}
+
+__global__ void select_init_kernel(uint32_t *state, uint32_t *hist, long n, int B)
+{
+    const int b = blockIdx.x;
+    hist[b * 256 + threadIdx.x] = 0;
+    if (threadIdx.x == 0) { state[b * 2] = 0; state[b * 2 + 1] = (uint32_t)((n - 1) / 2); }   // lower median
+}
+
+static size_t median_ws_bytes(int B) { return align_up((size_t)B * (2 + 256) * sizeof(uint32_t), 256); }
+
+static int slice_median_launch(const float *d_x, float *d_med, int B, long n, void *d_ws, hipStream_t st)
+{
+    uint32_t *state = (uint32_t *)d_ws;
+    uint32_t *hist = state + (size_t)B * 2;
+    hipLaunchKernelGGL(select_init_kernel, dim3(B), dim3(256), 0, st, state, hist, n, B);
+    int gx = cdiv(n, 256 * 8); if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(select_hist_kernel, dim3(gx, B), dim3(256), 0, st, d_x, n, state, hist, shift);
+        hipLaunchKernelGGL(select_scan_kernel, dim3(B), dim3(256), 0, st, state, hist, shift, d_med);
+    }
+    return IPDM_OK;
+}
+
+extern "C" int ipdm_slice_median(const float *d_x, float *d_med, int32_t B, int64_t n, void *d_ws, size_t ws_bytes,
+                                 void *stream)
+{
+    IPDM_REQUIRE(d_x && d_med && d_ws && B > 0 && n > 0, "slice_median: bad argument");
+    if (ws_bytes < median_ws_bytes(B)) { set_error("slice_median: workspace too small"); return IPDM_ERR_WORKSPACE; }
+    slice_median_launch(d_x, d_med, B, (long)n, d_ws, (hipStream_t)stream);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+// =============================================================================== guidance map
+struct Curve { double p1[5]; double p2[3]; };
+
+__device__ inline float miu2pixel_dev(float miu)
+{
+    // Dataset/npz_data_loader.py:20-36 in float32 (torch scalar rule casts the python constants)
+    float hu = (miu - 0.183f) * 1000.0f / 0.183f - 24.0f;
+    float img = (hu + 1024.0f) / 4096.0f;
+    if (hu < -1024.0f) img = 0.0f;
+    if (hu > 3072.0f) img = 1.0f;
+    return img;
+}
+
+__device__ inline float curve_eval(const Curve &cv, float e)
+{
+    // weight_lambda (Utils/train_test_utils.py:831-839), float64 Horner, float32 result
+    double x = (double)e;
+    double v;
+    if (x < 1) v = 1.0;
+    else if (x <= 1.7) v = x;
+    else if (x <= 2.75) v = x;
+    else v = 2.75;
+    double y = 0.0;
+    if (x <= 1.7) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) y = y * v + cv.p1[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) y = y * v + cv.p2[i];
+    }
+    return (float)y;
+}
+
+// proj: d = |x - img| at full resolution (median is taken on this)
+__global__ void __launch_bounds__(256) absdiff_kernel(const float *__restrict__ x, const float *__restrict__ img,
+                                                      float *__restrict__ d, long n)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) d[i] = fabsf(x[i] - img[i]);
+}
+
+// img: pooled = avg_pool(|miu2pixel(x) - miu2pixel(img)|) (median is taken on the pooled map)
+__global__ void __launch_bounds__(256) pool_absdiff_pixel_kernel(const float *__restrict__ x, const float *__restrict__ img,
+                                                                 float *__restrict__ pooled, int H, int W, int ks, int ph, int pw)
+{
+    const int b = blockIdx.y;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long)ph * pw) return;
+    const int py = (int)(q / pw), px = (int)(q % pw);
+    const float *sx = x + (size_t)b * H * W, *si = img + (size_t)b * H * W;
+    float acc = 0.0f;
+    for (int dy = 0; dy < ks; ++dy)
+        for (int dx = 0; dx < ks; ++dx) {
+            size_t o = (size_t)(py * ks + dy) * W + px * ks + dx;
+            acc += fabsf(miu2pixel_dev(sx[o]) - miu2pixel_dev(si[o]));
+        }
+    pooled[(size_t)b * ph * pw + q] = acc / (float)(ks * ks);
+}
+
+// proj: Lambda = curve(exp(amp * relu(avg_pool(d - med))));  img: Lambda = curve(exp(amp*relu(pooled - med)))
+__global__ void __launch_bounds__(256) guidance_finish_kernel(const float *__restrict__ src, const float *__restrict__ med,
+                                                              float *__restrict__ Lambda, float *__restrict__ expmax, int H, int W,
+                                                              int ks, int ph, int pw, float amp, int mode, Curve cv)
+{
+    const int b = blockIdx.y;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    float e = 0.0f;
+    if (q < (long)ph * pw) {
+        const float m = med[b];
+        float v;
+        if (mode == 1) {
+            const int py = (int)(q / pw), px = (int)(q % pw);
+            const float *s = src + (size_t)b * H * W;
+            float acc = 0.0f;
+            for (int dy = 0; dy < ks; ++dy)
+                for (int dx = 0; dx < ks; ++dx) acc += s[(size_t)(py * ks + dy) * W + px * ks + dx] - m;
+            v = acc / (float)(ks * ks);
+        } else {
+            v = src[(size_t)b * ph * pw + q] - m;
+        }
+        if (v <= 0.0f) v = 0.0f;
+        e = expf(amp * v);
+        Lambda[(size_t)b * ph * pw + q] = curve_eval(cv, e);
+    }
+    float mx = wave_max(e);
+    if ((threadIdx.x & 63) == 0 && expmax) atomicMax((int *)&expmax[b], __float_as_int(mx));   // e >= 0
+}
+
+extern "C" size_t ipdm_guidance_workspace_bytes(int32_t B, int32_t H, int32_t W)
+{
+    if (B <= 0) return 0;
+    return align_up((size_t)B * H * W * sizeof(float), 256) + median_ws_bytes(B) + align_up((size_t)B * sizeof(float), 256);
+}
+
+extern "C" int ipdm_guidance_map(const float *d_x, const float *d_img, float *d_Lambda, float *d_expmax, int32_t B,
+                                 int32_t H, int32_t W, int32_t ks, double amplitude, int32_t mode, const double *p1,
+                                 const double *p2, void *d_ws, size_t ws_bytes, void *stream)
+{
+    IPDM_REQUIRE(d_x && d_img && d_Lambda && d_ws && p1 && p2 && B > 0 && ks > 0 && H >= ks && W >= ks,
+                 "guidance_map: bad argument");
+    IPDM_REQUIRE(mode == 0 || mode == 1, "guidance_map: mode must be 0 (img) or 1 (proj)");
+    if (ws_bytes < ipdm_guidance_workspace_bytes(B, H, W)) { set_error("guidance_map: workspace too small"); return IPDM_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    char *w = (char *)d_ws;
+    float *d_tmp = (float *)w;
+    w += align_up((size_t)B * H * W * sizeof(float), 256);
+    void *d_sel = w;
+    w += median_ws_bytes(B);
+    float *d_med = (float *)w;
+    const int ph = H / ks, pw = W / ks;
+    Curve cv;
+    for (int i = 0; i < 5; ++i) cv.p1[i] = p1[i];
+    for (int i = 0; i < 3; ++i) cv.p2[i] = p2[i];
+    if (d_expmax) IPDM_HIP_CHECK(hipMemsetAsync(d_expmax, 0, (size_t)B * sizeof(float), st));
+    if (mode == 1) {
+        const long n = (long)B * H * W;
+        hipLaunchKernelGGL(absdiff_kernel, dim3(ew_grid(n)), dim3(256), 0, st, d_x, d_img, d_tmp, n);
+        slice_median_launch(d_tmp, d_med, B, (long)H * W, d_sel, st);
+    } else {
+        hipLaunchKernelGGL(pool_absdiff_pixel_kernel, dim3(cdiv((long)ph * pw, 256), B), dim3(256), 0, st, d_x, d_img,
+                           d_tmp, H, W, ks, ph, pw);
+        slice_median_launch(d_tmp, d_med, B, (long)ph * pw, d_sel, st);
+    }
+    hipLaunchKernelGGL(guidance_finish_kernel, dim3(cdiv((long)ph * pw, 256), B), dim3(256), 0, st, d_tmp, d_med,
+                       d_Lambda, d_expmax, H, W, ks, ph, pw, (float)amplitude, mode, cv);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+// condition_lambda_ratio_cuda (Model/model.py:340-351) + clip [0.05, 0.99] (:558)
+__global__ void __launch_bounds__(256) lambda_ratio_kernel(const float *__restrict__ L, float *__restrict__ out, long n,
+                                                           double c0, double c1, double c2)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        double lam = (double)L[i];
+        double a0 = pow(c0, lam), a1 = pow(c1, lam), a2 = pow(c2, lam);
+        a1 = a1 / a0;
+        a2 = a2 / a0;
+        float v = (float)(1 - (a2 / a1));
+        out[i] = fminf(fmaxf(v, 0.05f), 0.99f);
+    }
+}
+
+extern "C" int ipdm_lambda_ratio(const float *d_Lambda, float *d_out, int64_t n, int32_t i, int32_t ts, void *stream)
+{
+    IPDM_REQUIRE(d_Lambda && d_out && n > 0 && ts > 0 && i >= 0, "lambda_ratio: bad argument");
+    const double s = 0.008, pi = 3.141592653589793;
+    double c[3];
+    const int idx[3] = {0, i, i + 1};
+    for (int q = 0; q < 3; ++q) {
+        double v = cos((((double)idx[q] / (double)ts) + s) / (1 + s) * pi * 0.5);
+        c[q] = v * v;
+    }
+    hipLaunchKernelGGL(lambda_ratio_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, d_Lambda, d_out, (long)n,
+                       c[0], c[1], c[2]);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}

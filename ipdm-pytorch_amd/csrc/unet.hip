@@ -1,0 +1,789 @@
+// UNet epsilon-predictor executor for gfx950 (replaces UNetModel, Model/model.py:190-310).
+//
+// The module topology is rebuilt from the constructor arguments exactly as UNetModel.__init__ walks it
+// (:224-281), parameters are addressed by the reference's state_dict key names (so reference
+// checkpoints load unchanged) and repacked once into the kernels' layouts.  A forward is a fixed
+// sequence of launches on the caller's stream over a caller-provided workspace:
+//   time-embedding MLP + all per-block projections (2 tiny launches), then per block
+//   GN statistics -> conv (GN+SiLU prologue, bias/residual epilogue) ..., flash attention.
+// Activations are NCHW fp32; the workspace is carved by a first-fit arena whose schedule is replayed
+// identically on every call (ipdm_unet_workspace_bytes runs the same walk without launching).
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+#include "unet_kernels.h"
+
+using namespace ipdm;
+
+// ------------------------------------------------------------------------------------ small kernels
+namespace {
+
+__global__ void __launch_bounds__(256) temb_kernel(const float *__restrict__ freqs, int mc, float t,
+                                                   const float *__restrict__ w0, const float *__restrict__ b0,
+                                                   const float *__restrict__ w2, const float *__restrict__ b2,
+                                                   float *__restrict__ tmp, float *__restrict__ silu_emb)
+{
+    // single workgroup: sinusoid[mc] -> Linear(mc,4mc) -> SiLU -> Linear(4mc,4mc) -> SiLU (the SiLU of every
+    // ResidualBlock.time_emb, Model/model.py:105-108, is applied once here)
+    extern __shared__ float sm[];
+    float *e0 = sm;              // mc
+    float *h1 = sm + mc;         // 4mc
+    const int half = mc / 2, ted = 4 * mc;
+    for (int i = threadIdx.x; i < mc; i += 256) {
+        float v = 0.0f;
+        if (i < half) v = cosf(t * freqs[i]);
+        else if (i < 2 * half) v = sinf(t * freqs[i - half]);
+        e0[i] = v;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < ted; r += 256) {
+        float acc = 0.0f;
+        for (int k = 0; k < mc; ++k) acc += w0[(size_t)r * mc + k] * e0[k];
+        acc += b0[r];
+        h1[r] = acc / (1.0f + expf(-acc));
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < ted; r += 256) {
+        float acc = 0.0f;
+        for (int k = 0; k < ted; ++k) acc += w2[(size_t)r * ted + k] * h1[k];
+        acc += b2[r];
+        tmp[r] = acc;
+        silu_emb[r] = acc / (1.0f + expf(-acc));
+    }
+}
+
+// one wave per output row
+__global__ void __launch_bounds__(256) gemv_bias_kernel(const float *__restrict__ W, const float *__restrict__ b,
+                                                        const float *__restrict__ base, const float *__restrict__ v,
+                                                        float *__restrict__ y, int rows, int K)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float acc = 0.0f;
+    for (int k = lane; k < K; k += 64) acc += W[(size_t)row * K + k] * v[k];
+    acc = wave_sum(acc);
+    if (lane == 0) y[row] = base[row] + (acc + b[row]);
+}
+
+__global__ void __launch_bounds__(256) concat_kernel(const float *__restrict__ x1, const float *__restrict__ x2,
+                                                     float *__restrict__ out, int C1, int C2, long HW, long total)
+{
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const int Ct = C1 + C2;
+    for (; i < total; i += stride) {
+        const long hw = i % HW;
+        const long nc = i / HW;
+        const int c = (int)(nc % Ct);
+        const long n = nc / Ct;
+        out[i] = c < C1 ? x1[(n * C1 + c) * HW + hw] : x2[(n * C2 + (c - C1)) * HW + hw];
+    }
+}
+
+}  // namespace
+
+namespace ipdm {
+int temb_launch(const float *freqs, int mc, int t, const float *w0, const float *b0, const float *w2, const float *b2,
+                float *tmp, float *silu_emb, hipStream_t st)
+{
+    hipLaunchKernelGGL(temb_kernel, dim3(1), dim3(256), (size_t)5 * mc * sizeof(float), st, freqs, mc, (float)t, w0, b0,
+                       w2, b2, tmp, silu_emb);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+int gemv_bias_launch(const float *W, const float *b, const float *base, const float *v, float *y, int rows, int K,
+                     hipStream_t st)
+{
+    hipLaunchKernelGGL(gemv_bias_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, W, b, base, v, y, rows, K);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+}  // namespace ipdm
+
+// ------------------------------------------------------------------------------------ topology
+namespace {
+
+enum LayerKind { L_CONV, L_RES, L_ATTN, L_DOWN, L_UP };
+struct Layer { LayerKind kind; int cin, cout; std::string prefix; };
+struct Topology {
+    std::vector<std::vector<Layer>> down, up;
+    std::vector<Layer> middle;
+    int out_ch_in;      // channels entering self.out
+    int ted;            // time embedding dim
+};
+
+// norm_layer / factor (Model/model.py:69-90)
+int gn_groups(int ch)
+{
+    if (ch % 32 == 0) return 32;
+    if (ch < 32) return ch;
+    std::vector<int> f;
+    int lim = (int)std::sqrt((double)ch);
+    for (int i = 1; i <= lim; ++i)
+        if (ch % i == 0) {
+            f.push_back(i);
+            int t = ch / i;
+            if (t != i) f.push_back(t);
+        }
+    int best = f[0];
+    long bd = (long)(f[0] - 32) * (f[0] - 32);
+    for (size_t k = 1; k < f.size(); ++k) {
+        long dd = (long)(f[k] - 32) * (f[k] - 32);
+        if (dd < bd) { bd = dd; best = f[k]; }      // first argmin
+    }
+    return best;
+}
+
+std::string pfx(const char *blk, int bi, int li)
+{
+    char buf[64];
+    if (bi >= 0) snprintf(buf, sizeof buf, "%s.%d.%d", blk, bi, li);
+    else snprintf(buf, sizeof buf, "%s.%d", blk, li);
+    return buf;
+}
+
+bool in_attn(const ipdm_unet_cfg &c, int ds)
+{
+    for (int i = 0; i < c.n_attn; ++i)
+        if (c.attention_resolutions[i] == ds) return true;
+    return false;
+}
+
+// mirrors UNetModel.__init__ (Model/model.py:224-281); int(mult*model_channels) truncation included
+Topology build_topology(const ipdm_unet_cfg &c)
+{
+    Topology t;
+    const int mc = c.model_channels;
+    t.ted = 4 * mc;
+    int ch = (int)(c.channel_mult[0] * mc);
+    t.down.push_back({Layer{L_CONV, c.in_channels, ch, pfx("down_blocks", 0, 0)}});
+    std::vector<int> chans{ch};
+    int ds = 1;
+    const int nlev = c.n_mult - 1;
+    for (int level = 0; level < nlev; ++level) {
+        const double mult = c.channel_mult[level + 1];
+        for (int r = 0; r < c.num_res_blocks; ++r) {
+            const int bi = (int)t.down.size();
+            std::vector<Layer> layers;
+            const int co = (int)(mult * mc);
+            layers.push_back(Layer{L_RES, ch, co, pfx("down_blocks", bi, 0)});
+            ch = co;
+            if (in_attn(c, ds)) layers.push_back(Layer{L_ATTN, ch, ch, pfx("down_blocks", bi, 1)});
+            t.down.push_back(layers);
+            chans.push_back(ch);
+        }
+        if (level != nlev - 1) {
+            const int bi = (int)t.down.size();
+            t.down.push_back({Layer{L_DOWN, ch, ch, pfx("down_blocks", bi, 0)}});
+            chans.push_back(ch);
+            ds *= 2;
+        }
+    }
+    t.middle = {Layer{L_RES, ch, ch, pfx("middle_block", -1, 0)}, Layer{L_ATTN, ch, ch, pfx("middle_block", -1, 1)},
+                Layer{L_RES, ch, ch, pfx("middle_block", -1, 2)}};
+    for (int level = nlev - 1; level >= 0; --level) {
+        const double mult = c.channel_mult[level + 1];
+        for (int i = 0; i <= c.num_res_blocks; ++i) {
+            const int bi = (int)t.up.size();
+            std::vector<Layer> layers;
+            const int skip = chans.back();
+            chans.pop_back();
+            const int co = (int)(mc * mult);
+            layers.push_back(Layer{L_RES, ch + skip, co, pfx("up_blocks", bi, 0)});
+            ch = co;
+            if (in_attn(c, ds)) layers.push_back(Layer{L_ATTN, ch, ch, pfx("up_blocks", bi, (int)layers.size())});
+            if (level && i == c.num_res_blocks) {
+                layers.push_back(Layer{L_UP, ch, ch, pfx("up_blocks", bi, (int)layers.size())});
+                ds /= 2;
+            }
+            t.up.push_back(layers);
+        }
+    }
+    t.out_ch_in = ch;
+    return t;
+}
+
+struct ParamInfo { std::string name; int shape[4]; int ndim; };
+
+void add_p(std::vector<ParamInfo> &v, const std::string &name, int a, int b = 0, int c = 0, int d = 0)
+{
+    ParamInfo p;
+    p.name = name;
+    p.shape[0] = a; p.shape[1] = b ? b : 1; p.shape[2] = c ? c : 1; p.shape[3] = d ? d : 1;
+    p.ndim = d ? 4 : (c ? 3 : (b ? 2 : 1));
+    v.push_back(p);
+}
+
+void layer_params(std::vector<ParamInfo> &v, const Layer &l, int ted)
+{
+    const std::string &p = l.prefix;
+    switch (l.kind) {
+        case L_CONV:
+            add_p(v, p + ".weight", l.cout, l.cin, 3, 3); add_p(v, p + ".bias", l.cout); break;
+        case L_RES:
+            add_p(v, p + ".conv1.0.weight", l.cin); add_p(v, p + ".conv1.0.bias", l.cin);
+            add_p(v, p + ".conv1.2.weight", l.cout, l.cin, 3, 3); add_p(v, p + ".conv1.2.bias", l.cout);
+            add_p(v, p + ".time_emb.1.weight", l.cout, ted); add_p(v, p + ".time_emb.1.bias", l.cout);
+            add_p(v, p + ".conv2.0.weight", l.cout); add_p(v, p + ".conv2.0.bias", l.cout);
+            add_p(v, p + ".conv2.2.weight", l.cout, l.cout, 3, 3); add_p(v, p + ".conv2.2.bias", l.cout);
+            if (l.cin != l.cout) { add_p(v, p + ".shortcut.weight", l.cout, l.cin, 1, 1); add_p(v, p + ".shortcut.bias", l.cout); }
+            break;
+        case L_ATTN:
+            add_p(v, p + ".norm.weight", l.cin); add_p(v, p + ".norm.bias", l.cin);
+            add_p(v, p + ".qkv.weight", 3 * l.cin, l.cin, 1, 1);
+            add_p(v, p + ".proj.weight", l.cin, l.cin, 1, 1); add_p(v, p + ".proj.bias", l.cin);
+            break;
+        case L_DOWN:
+            add_p(v, p + ".op.weight", l.cout, l.cin, 3, 3); add_p(v, p + ".op.bias", l.cout); break;
+        case L_UP:
+            add_p(v, p + ".conv.weight", l.cout, l.cin, 3, 3); add_p(v, p + ".conv.bias", l.cout); break;
+    }
+}
+
+std::vector<ParamInfo> list_params(const ipdm_unet_cfg &c, const Topology &t)
+{
+    std::vector<ParamInfo> v;
+    const int mc = c.model_channels;
+    add_p(v, "time_embed.0.weight", t.ted, mc); add_p(v, "time_embed.0.bias", t.ted);
+    add_p(v, "time_embed.2.weight", t.ted, t.ted); add_p(v, "time_embed.2.bias", t.ted);
+    for (auto &blk : t.down) for (auto &l : blk) layer_params(v, l, t.ted);
+    for (auto &l : t.middle) layer_params(v, l, t.ted);
+    for (auto &blk : t.up) for (auto &l : blk) layer_params(v, l, t.ted);
+    add_p(v, "out.0.weight", t.out_ch_in); add_p(v, "out.0.bias", t.out_ch_in);
+    add_p(v, "out.2.weight", c.out_channels, t.out_ch_in, 3, 3); add_p(v, "out.2.bias", c.out_channels);
+    return v;
+}
+
+bool cfg_ok(const ipdm_unet_cfg *c)
+{
+    return c && c->in_channels > 0 && c->model_channels > 0 && c->out_channels > 0 && c->num_res_blocks > 0 &&
+           c->num_heads > 0 && c->n_mult >= 2 && c->n_mult <= 16 && c->n_attn >= 0 && c->n_attn <= 16;
+}
+
+}  // namespace
+
+extern "C" int ipdm_unet_param_count(const ipdm_unet_cfg *cfg)
+{
+    if (!cfg_ok(cfg)) { set_error("unet_param_count: bad config"); return IPDM_ERR_INVALID; }
+    Topology t = build_topology(*cfg);
+    return (int)list_params(*cfg, t).size();
+}
+
+extern "C" int ipdm_unet_param_info(const ipdm_unet_cfg *cfg, int32_t idx, char *name, int32_t name_cap, int32_t shape[4],
+                                    int32_t *ndim)
+{
+    if (!cfg_ok(cfg)) { set_error("unet_param_info: bad config"); return IPDM_ERR_INVALID; }
+    Topology t = build_topology(*cfg);
+    auto v = list_params(*cfg, t);
+    IPDM_REQUIRE(idx >= 0 && idx < (int)v.size() && name && shape && ndim, "unet_param_info: bad index %d", idx);
+    snprintf(name, name_cap, "%s", v[idx].name.c_str());
+    for (int i = 0; i < 4; ++i) shape[i] = v[idx].shape[i];
+    *ndim = v[idx].ndim;
+    return IPDM_OK;
+}
+
+// ------------------------------------------------------------------------------------ the net
+namespace {
+
+struct ConvP { float *w = nullptr; float *b = nullptr; int cin = 0, cout = 0, ks = 0, cout_pad = 0; };
+struct NormP { float *g = nullptr, *b = nullptr; int ch = 0, groups = 0; };
+struct ResP { NormP n1, n2; ConvP c1, c2, sc; bool has_sc = false; int bias_off = 0; };   // bias_off into bias_eff
+struct AttnP { NormP n; ConvP qkv, proj; };
+
+struct Arena {
+    // first-fit free list over a byte range; replayed identically on every forward
+    struct Blk { size_t off, size; };
+    std::vector<Blk> free_;
+    size_t cap = 0, high = 0;
+    void reset(size_t capacity) { cap = capacity; free_.assign(1, Blk{0, capacity}); high = 0; }
+    size_t alloc(size_t bytes)
+    {
+        bytes = align_up(bytes ? bytes : 1, 256);
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].size >= bytes) {
+                size_t off = free_[i].off;
+                free_[i].off += bytes;
+                free_[i].size -= bytes;
+                if (!free_[i].size) free_.erase(free_.begin() + i);
+                if (off + bytes > high) high = off + bytes;
+                return off;
+            }
+        return (size_t)-1;
+    }
+    void release(size_t off, size_t bytes)
+    {
+        bytes = align_up(bytes ? bytes : 1, 256);
+        size_t i = 0;
+        while (i < free_.size() && free_[i].off < off) ++i;
+        free_.insert(free_.begin() + i, Blk{off, bytes});
+        if (i + 1 < free_.size() && free_[i].off + free_[i].size == free_[i + 1].off) {
+            free_[i].size += free_[i + 1].size;
+            free_.erase(free_.begin() + i + 1);
+        }
+        if (i > 0 && free_[i - 1].off + free_[i - 1].size == free_[i].off) {
+            free_[i - 1].size += free_[i].size;
+            free_.erase(free_.begin() + i);
+        }
+    }
+};
+
+struct Tensor { size_t off = (size_t)-1; size_t bytes = 0; int C = 0, H = 0, W = 0; int refs = 0; bool external = false; const float *ext = nullptr; };
+
+}  // namespace
+
+struct ipdm_unet {
+    ipdm_unet_cfg cfg;
+    Topology topo;
+    std::vector<float *> owned;                 // device allocations
+    std::map<std::string, ConvP> convs;
+    std::map<std::string, ResP> res;
+    std::map<std::string, AttnP> attn;
+    NormP out_norm;
+    ConvP out_conv;
+    float *d_freqs = nullptr, *te_w0 = nullptr, *te_b0 = nullptr, *te_w2 = nullptr, *te_b2 = nullptr;
+    float *temb_W = nullptr, *temb_b = nullptr, *conv1_b = nullptr;   // concatenated over all ResidualBlocks
+    int temb_rows = 0;
+    int max_gn_groups = 32, max_ch = 0;
+
+    // forward state
+    Arena arena;
+    char *ws = nullptr;
+    bool dry = false;
+    hipStream_t st = nullptr;
+    int B = 0;
+    float *bias_eff = nullptr, *gn_scale = nullptr, *gn_shift = nullptr;
+    double *gn_part = nullptr;
+    std::vector<Tensor *> live;
+};
+
+namespace {
+
+int upload(ipdm_unet *net, const float *host, size_t n, float **out)
+{
+    float *d = nullptr;
+    IPDM_HIP_CHECK(hipMalloc((void **)&d, (n ? n : 1) * sizeof(float)));
+    if (n) IPDM_HIP_CHECK(hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice));
+    net->owned.push_back(d);
+    *out = d;
+    return IPDM_OK;
+}
+
+struct WeightMap {
+    std::map<std::string, const float *> m;
+    const float *get(const std::string &k) const
+    {
+        auto it = m.find(k);
+        return it == m.end() ? nullptr : it->second;
+    }
+};
+
+int make_conv(ipdm_unet *net, const WeightMap &wm, const std::string &wname, const std::string &bname, int cout, int cin,
+              int ks, ConvP &out)
+{
+    const float *w = wm.get(wname);
+    IPDM_REQUIRE(w, "unet_create: missing parameter %s", wname.c_str());
+    std::vector<float> packed;
+    int cin_pad, cout_pad;
+    conv_pack_weights(w, cout, cin, ks, packed, cin_pad, cout_pad);
+    out.cin = cin; out.cout = cout; out.ks = ks; out.cout_pad = cout_pad;
+    int rc = upload(net, packed.data(), packed.size(), &out.w);
+    if (rc) return rc;
+    out.b = nullptr;
+    if (!bname.empty()) {
+        const float *b = wm.get(bname);
+        IPDM_REQUIRE(b, "unet_create: missing parameter %s", bname.c_str());
+        rc = upload(net, b, cout, &out.b);
+    }
+    return rc;
+}
+
+int make_norm(ipdm_unet *net, const WeightMap &wm, const std::string &p, int ch, NormP &out)
+{
+    const float *g = wm.get(p + ".weight"), *b = wm.get(p + ".bias");
+    IPDM_REQUIRE(g && b, "unet_create: missing parameter %s.{weight,bias}", p.c_str());
+    out.ch = ch;
+    out.groups = gn_groups(ch);
+    int rc = upload(net, g, ch, &out.g);
+    if (rc) return rc;
+    if (out.groups > net->max_gn_groups) net->max_gn_groups = out.groups;
+    if (ch > net->max_ch) net->max_ch = ch;
+    return upload(net, b, ch, &out.b);
+}
+
+}  // namespace
+
+extern "C" int ipdm_unet_create(const ipdm_unet_cfg *cfg, const float *const *weights, int32_t n_weights, ipdm_unet **out)
+{
+    IPDM_REQUIRE(cfg_ok(cfg) && weights && out, "unet_create: bad argument");
+    IPDM_REQUIRE(cfg->model_channels % 2 == 0, "unet_create: model_channels must be even");
+    ipdm_unet *net = new ipdm_unet();
+    net->cfg = *cfg;
+    net->topo = build_topology(*cfg);
+    auto plist = list_params(*cfg, net->topo);
+    if ((int)plist.size() != n_weights) {
+        set_error("unet_create: expected %d parameters, got %d", (int)plist.size(), n_weights);
+        delete net;
+        return IPDM_ERR_INVALID;
+    }
+    WeightMap wm;
+    for (size_t i = 0; i < plist.size(); ++i) {
+        if (!weights[i]) { set_error("unet_create: parameter %s is null", plist[i].name.c_str()); delete net; return IPDM_ERR_INVALID; }
+        wm.m[plist[i].name] = weights[i];
+    }
+    const int mc = cfg->model_channels, ted = net->topo.ted;
+    int rc = 0;
+#define TRY(x) do { rc = (x); if (rc) { ipdm_unet_destroy(net); return rc; } } while (0)
+    // sinusoid frequencies in float32 exactly as timestep_embedding builds them (Model/model.py:24-27):
+    // exp(-log(1e4) * arange(half) / half) evaluated in float32
+    {
+        const int half = mc / 2;
+        std::vector<float> f(half);
+        const float a = (float)(-std::log(10000.0));
+        for (int k = 0; k < half; ++k) f[k] = expf((a * (float)k) / (float)half);
+        TRY(upload(net, f.data(), half, &net->d_freqs));
+    }
+    TRY(upload(net, wm.get("time_embed.0.weight"), (size_t)ted * mc, &net->te_w0));
+    TRY(upload(net, wm.get("time_embed.0.bias"), ted, &net->te_b0));
+    TRY(upload(net, wm.get("time_embed.2.weight"), (size_t)ted * ted, &net->te_w2));
+    TRY(upload(net, wm.get("time_embed.2.bias"), ted, &net->te_b2));
+
+    std::vector<float> tW, tb, c1b;
+    auto do_layer = [&](const Layer &l) -> int {
+        const std::string &p = l.prefix;
+        int r = 0;
+        switch (l.kind) {
+            case L_CONV: r = make_conv(net, wm, p + ".weight", p + ".bias", l.cout, l.cin, 3, net->convs[p]); break;
+            case L_DOWN: r = make_conv(net, wm, p + ".op.weight", p + ".op.bias", l.cout, l.cin, 3, net->convs[p]); break;
+            case L_UP: r = make_conv(net, wm, p + ".conv.weight", p + ".conv.bias", l.cout, l.cin, 3, net->convs[p]); break;
+            case L_RES: {
+                ResP &rp = net->res[p];
+                if ((r = make_norm(net, wm, p + ".conv1.0", l.cin, rp.n1))) break;
+                if ((r = make_conv(net, wm, p + ".conv1.2.weight", "", l.cout, l.cin, 3, rp.c1))) break;
+                if ((r = make_norm(net, wm, p + ".conv2.0", l.cout, rp.n2))) break;
+                if ((r = make_conv(net, wm, p + ".conv2.2.weight", p + ".conv2.2.bias", l.cout, l.cout, 3, rp.c2))) break;
+                rp.has_sc = l.cin != l.cout;
+                if (rp.has_sc && (r = make_conv(net, wm, p + ".shortcut.weight", p + ".shortcut.bias", l.cout, l.cin, 1, rp.sc))) break;
+                const float *tw = wm.get(p + ".time_emb.1.weight"), *tbb = wm.get(p + ".time_emb.1.bias"),
+                            *cb = wm.get(p + ".conv1.2.bias");
+                if (!tw || !tbb || !cb) { set_error("unet_create: missing time_emb/conv1 bias of %s", p.c_str()); r = IPDM_ERR_INVALID; break; }
+                rp.bias_off = (int)tb.size();
+                tW.insert(tW.end(), tw, tw + (size_t)l.cout * ted);
+                tb.insert(tb.end(), tbb, tbb + l.cout);
+                c1b.insert(c1b.end(), cb, cb + l.cout);
+                break;
+            }
+            case L_ATTN: {
+                AttnP &ap = net->attn[p];
+                if ((r = make_norm(net, wm, p + ".norm", l.cin, ap.n))) break;
+                if ((r = make_conv(net, wm, p + ".qkv.weight", "", 3 * l.cin, l.cin, 1, ap.qkv))) break;
+                r = make_conv(net, wm, p + ".proj.weight", p + ".proj.bias", l.cin, l.cin, 1, ap.proj);
+                if (!r && l.cin / cfg->num_heads != 64) { set_error("unet_create: attention head dim %d unsupported (64 only)", l.cin / cfg->num_heads); r = IPDM_ERR_UNSUPPORTED; }
+                break;
+            }
+        }
+        return r;
+    };
+    for (auto &blk : net->topo.down) for (auto &l : blk) TRY(do_layer(l));
+    for (auto &l : net->topo.middle) TRY(do_layer(l));
+    for (auto &blk : net->topo.up) for (auto &l : blk) TRY(do_layer(l));
+    TRY(make_norm(net, wm, "out.0", net->topo.out_ch_in, net->out_norm));
+    TRY(make_conv(net, wm, "out.2.weight", "out.2.bias", cfg->out_channels, net->topo.out_ch_in, 3, net->out_conv));
+    net->temb_rows = (int)tb.size();
+    TRY(upload(net, tW.data(), tW.size(), &net->temb_W));
+    TRY(upload(net, tb.data(), tb.size(), &net->temb_b));
+    TRY(upload(net, c1b.data(), c1b.size(), &net->conv1_b));
+#undef TRY
+    // the largest GN input is a concatenated up-block input
+    for (auto &blk : net->topo.up) for (auto &l : blk) if (l.cin > net->max_ch) net->max_ch = l.cin;
+    *out = net;
+    return IPDM_OK;
+}
+
+extern "C" int ipdm_unet_destroy(ipdm_unet *net)
+{
+    if (!net) return IPDM_OK;
+    for (float *p : net->owned) (void)hipFree(p);
+    delete net;
+    return IPDM_OK;
+}
+
+// ------------------------------------------------------------------------------------ forward walk
+namespace {
+
+struct Fwd {
+    ipdm_unet *net;
+    int rc = 0;
+
+    const float *ptr(const Tensor *t) const { return t->external ? t->ext : (const float *)(net->ws + t->off); }
+    float *wptr(Tensor *t) const { return (float *)(net->ws + t->off); }
+
+    Tensor *make(int C, int H, int W)
+    {
+        Tensor *t = new Tensor();
+        t->C = C; t->H = H; t->W = W;
+        t->bytes = (size_t)net->B * C * H * W * sizeof(float);
+        t->off = net->arena.alloc(t->bytes);
+        if (t->off == (size_t)-1) { set_error("unet_forward: workspace exhausted"); rc = IPDM_ERR_WORKSPACE; t->off = 0; }
+        t->refs = 1;
+        net->live.push_back(t);
+        return t;
+    }
+    void retain(Tensor *t) { t->refs++; }
+    void release(Tensor *t)
+    {
+        if (--t->refs == 0) {
+            if (!t->external) net->arena.release(t->off, t->bytes);
+            for (size_t i = 0; i < net->live.size(); ++i)
+                if (net->live[i] == t) { net->live.erase(net->live.begin() + i); break; }
+            delete t;
+        }
+    }
+
+    void gn(const Tensor *x1, const Tensor *x2, const NormP &np)
+    {
+        if (rc || net->dry) return;
+        GnArgs a;
+        a.x1 = ptr(x1); a.x2 = x2 ? ptr(x2) : nullptr;
+        a.C1 = x1->C; a.C2 = x2 ? x2->C : 0; a.B = net->B;
+        a.HW = (long)x1->H * x1->W;
+        a.groups = np.groups; a.gamma = np.g; a.beta = np.b; a.eps = 1e-5f;
+        a.partials = net->gn_part; a.scale = net->gn_scale; a.shift = net->gn_shift;
+        rc = gn_stats_launch(a, net->st);
+    }
+
+    // conv over (x1 [,x2]) optionally nearest-upsampled to (H,W); returns a new tensor
+    Tensor *conv(const Tensor *x1, const Tensor *x2, const ConvP &cp, int stride, int act, const float *bias,
+                 const Tensor *res, int H, int W, float *ext_out = nullptr)
+    {
+        const int pad = cp.ks / 2;
+        const int Ho = (H + 2 * pad - cp.ks) / stride + 1, Wo = (W + 2 * pad - cp.ks) / stride + 1;
+        Tensor *o;
+        if (ext_out) { o = new Tensor(); o->C = cp.cout; o->H = Ho; o->W = Wo; o->external = true; o->ext = ext_out; o->refs = 1; net->live.push_back(o); }
+        else o = make(cp.cout, Ho, Wo);
+        if (rc || net->dry) return o;
+        ConvArgs a;
+        a.x1 = ptr(x1); a.x2 = x2 ? ptr(x2) : nullptr;
+        a.C1 = x1->C; a.C2 = x2 ? x2->C : 0; a.B = net->B;
+        a.Hs = x1->H; a.Ws = x1->W; a.H = H; a.W = W;
+        a.upsample = (H != x1->H || W != x1->W);
+        a.scale_y = (float)x1->H / (float)H; a.scale_x = (float)x1->W / (float)W;
+        a.w = cp.w; a.cout_pad = cp.cout_pad; a.bias = bias; a.Cout = cp.cout; a.ksize = cp.ks; a.stride = stride;
+        a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = net->gn_scale; a.gn_shift = net->gn_shift;
+        a.res = res ? ptr(res) : nullptr;
+        a.out = ext_out ? ext_out : wptr(o);
+        a.tiles_x = a.tiles_y = a.co_tiles = 0;
+        rc = conv2d_launch(a, net->st);
+        return o;
+    }
+
+    // ResidualBlock.forward (Model/model.py:121-130); consumes nothing, returns new tensor
+    Tensor *res_block(const Tensor *x1, const Tensor *x2, const Layer &l)
+    {
+        const ResP &rp = net->res[l.prefix];
+        const int H = x1->H, W = x1->W;
+        gn(x1, x2, rp.n1);
+        Tensor *h1 = conv(x1, x2, rp.c1, 1, 2, net->bias_eff + rp.bias_off, nullptr, H, W);
+        Tensor *sc = nullptr;
+        const Tensor *resid;
+        if (rp.has_sc) { sc = conv(x1, x2, rp.sc, 1, 0, rp.sc.b, nullptr, H, W); resid = sc; }
+        else if (x2) {   // identity shortcut over a concatenated input: materialise the concat
+            sc = make(x1->C + x2->C, H, W);
+            if (!rc && !net->dry) {
+                const long total = (long)net->B * (x1->C + x2->C) * H * W;
+                int g = cdiv(total, 1024); if (g > 4096) g = 4096;
+                hipLaunchKernelGGL(concat_kernel, dim3(g), dim3(256), 0, net->st, ptr(x1), ptr(x2), wptr(sc), x1->C, x2->C, (long)H * W, total);
+            }
+            resid = sc;
+        } else resid = x1;
+        gn(h1, nullptr, rp.n2);
+        Tensor *o = conv(h1, nullptr, rp.c2, 1, 2, rp.c2.b, resid, H, W);
+        release(h1);
+        if (sc) release(sc);
+        return o;
+    }
+
+    // AttentionBlock.forward (Model/model.py:145-155)
+    Tensor *attn_block(const Tensor *x, const Layer &l)
+    {
+        const AttnP &ap = net->attn[l.prefix];
+        const int H = x->H, W = x->W;
+        gn(x, nullptr, ap.n);
+        Tensor *qkv = conv(x, nullptr, ap.qkv, 1, 1, nullptr, nullptr, H, W);
+        Tensor *a = make(x->C, H, W);
+        if (!rc && !net->dry) rc = attention_launch(ptr(qkv), wptr(a), net->B, net->cfg.num_heads, x->C / net->cfg.num_heads, H * W, net->st);
+        release(qkv);
+        Tensor *o = conv(a, nullptr, ap.proj, 1, 0, ap.proj.b, x, H, W);
+        release(a);
+        return o;
+    }
+
+    // TimestepEmbedSequential.forward (Model/model.py:55-63) over one block's layers.
+    // (x1,x2) is the (possibly concatenated) block input; the caller keeps ownership of x1/x2.
+    Tensor *run_block(const std::vector<Layer> &layers, Tensor *x1, Tensor *x2, int size_h, int size_w)
+    {
+        Tensor *h = nullptr;
+        for (size_t i = 0; i < layers.size(); ++i) {
+            const Layer &l = layers[i];
+            const Tensor *in1 = h ? h : x1;
+            const Tensor *in2 = h ? nullptr : x2;
+            Tensor *o = nullptr;
+            switch (l.kind) {
+                case L_CONV: { const ConvP &cp = net->convs[l.prefix]; o = conv(in1, in2, cp, 1, 0, cp.b, nullptr, in1->H, in1->W); break; }
+                case L_DOWN: { const ConvP &cp = net->convs[l.prefix]; o = conv(in1, in2, cp, 2, 0, cp.b, nullptr, in1->H, in1->W); break; }
+                case L_UP: { const ConvP &cp = net->convs[l.prefix]; o = conv(in1, in2, cp, 1, 0, cp.b, nullptr, size_h, size_w); break; }
+                case L_RES: o = res_block(in1, in2, l); break;
+                case L_ATTN: o = attn_block(in1, l); break;
+            }
+            if (h) release(h);
+            h = o;
+        }
+        return h;
+    }
+};
+
+size_t fixed_ws_bytes(const ipdm_unet *net, int B)
+{
+    size_t s = 0;
+    s += align_up((size_t)net->topo.ted * 2 * sizeof(float), 256);              // emb tmp + silu(emb)
+    s += align_up((size_t)(net->temb_rows ? net->temb_rows : 1) * sizeof(float), 256);   // bias_eff
+    s += 2 * align_up((size_t)B * net->max_ch * sizeof(float), 256);             // gn scale/shift
+    s += align_up(gn_partials_bytes(B, net->max_gn_groups), 256);
+    return s;
+}
+
+int run_forward(ipdm_unet *net, const float *d_x, int t, float *d_eps, int B, int H, int W, void *d_ws, size_t ws_bytes,
+                hipStream_t st, bool dry, size_t *need)
+{
+    net->B = B; net->st = st; net->dry = dry; net->ws = (char *)d_ws;
+    const size_t fixed = fixed_ws_bytes(net, B);
+    if (!dry && ws_bytes < fixed) { set_error("unet_forward: workspace too small"); return IPDM_ERR_WORKSPACE; }
+    // fixed region
+    char *w = (char *)d_ws;
+    float *emb_tmp = (float *)w; float *silu_emb = emb_tmp + net->topo.ted;
+    w += align_up((size_t)net->topo.ted * 2 * sizeof(float), 256);
+    net->bias_eff = (float *)w; w += align_up((size_t)(net->temb_rows ? net->temb_rows : 1) * sizeof(float), 256);
+    net->gn_scale = (float *)w; w += align_up((size_t)B * net->max_ch * sizeof(float), 256);
+    net->gn_shift = (float *)w; w += align_up((size_t)B * net->max_ch * sizeof(float), 256);
+    net->gn_part = (double *)w;
+    net->ws = (char *)d_ws + fixed;
+    net->arena.reset(dry ? (size_t)1 << 46 : ws_bytes - fixed);
+    for (Tensor *tt : net->live) delete tt;
+    net->live.clear();
+
+    Fwd f{net};
+    if (!dry) {
+        f.rc = temb_launch(net->d_freqs, net->cfg.model_channels, t, net->te_w0, net->te_b0, net->te_w2, net->te_b2, emb_tmp, silu_emb, st);
+        if (!f.rc && net->temb_rows)
+            f.rc = gemv_bias_launch(net->temb_W, net->temb_b, net->conv1_b, silu_emb, net->bias_eff, net->temb_rows, net->topo.ted, st);
+    }
+    Tensor *x = new Tensor();
+    x->C = net->cfg.in_channels; x->H = H; x->W = W; x->external = true; x->ext = d_x; x->refs = 1;
+    net->live.push_back(x);
+
+    std::vector<Tensor *> hs;
+    Tensor *h = x;
+    for (auto &blk : net->topo.down) {
+        Tensor *o = f.run_block(blk, h, nullptr, 0, 0);
+        f.release(h);              // drops the block input unless it is held as a skip
+        h = o;
+        f.retain(h);
+        hs.push_back(h);
+    }
+    {
+        Tensor *o = f.run_block(net->topo.middle, h, nullptr, 0, 0);
+        f.release(h);
+        h = o;
+    }
+    Tensor *h_ = hs.back(); hs.pop_back();     // refs held by hs transfer to h_
+    for (auto &blk : net->topo.up) {
+        Tensor *skip = h_;
+        bool popped = false;
+        if (!hs.empty()) { h_ = hs.back(); hs.pop_back(); popped = true; }   // quirk of Model/model.py:304-309
+        Tensor *o = f.run_block(blk, h, skip, h_->H, h_->W);
+        f.release(h);
+        if (popped) f.release(skip);    // the consumed skip; when nothing was popped, `skip` is still h_ (reused next)
+        h = o;
+    }
+    f.release(h_);
+    // out = Conv(SiLU(GN(h)))  (Model/model.py:277-281,310)
+    f.gn(h, nullptr, net->out_norm);
+    Tensor *eps = f.conv(h, nullptr, net->out_conv, 1, 2, net->out_conv.b, nullptr, h->H, h->W, dry ? reinterpret_cast<float *>((uintptr_t)256) : d_eps);
+    f.release(h);
+    f.release(eps);
+    if (need) *need = fixed + net->arena.high;
+    for (Tensor *tt : net->live) delete tt;
+    net->live.clear();
+    return f.rc;
+}
+
+}  // namespace
+
+extern "C" size_t ipdm_unet_workspace_bytes(ipdm_unet *net, int32_t B, int32_t H, int32_t W)
+{
+    if (!net || B <= 0 || H <= 0 || W <= 0) return 0;
+    size_t need = 0;
+    run_forward(net, nullptr, 0, nullptr, B, H, W, nullptr, 0, nullptr, true, &need);
+    return need;
+}
+
+extern "C" int ipdm_unet_forward(ipdm_unet *net, const float *d_x, int32_t t, float *d_eps, int32_t B, int32_t H, int32_t W,
+                                 void *d_ws, size_t ws_bytes, void *stream)
+{
+    IPDM_REQUIRE(net && d_x && d_eps && d_ws && B > 0 && H > 0 && W > 0 && t >= 0, "unet_forward: bad argument");
+    return run_forward(net, d_x, t, d_eps, B, H, W, d_ws, ws_bytes, (hipStream_t)stream, false, nullptr);
+}
+
+// ------------------------------------------------------------------------------------ op-level entry (tests)
+extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, int32_t C2, int32_t B, int32_t Hs, int32_t Ws,
+                              int32_t H, int32_t W, const float *w_host, const float *b_host, int32_t Cout, int32_t ksize,
+                              int32_t stride, int32_t act, int32_t groups, const float *gamma_host, const float *beta_host,
+                              const float *d_res, float *d_out, void *stream)
+{
+    IPDM_REQUIRE(d_x1 && w_host && d_out, "op_conv2d: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int Cin = C1 + C2;
+    std::vector<float> packed;
+    int cin_pad, cout_pad;
+    conv_pack_weights(w_host, Cout, Cin, ksize, packed, cin_pad, cout_pad);
+    float *d_w = nullptr, *d_b = nullptr, *d_g = nullptr, *d_be = nullptr, *d_sc = nullptr, *d_sh = nullptr;
+    double *d_part = nullptr;
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_w, packed.size() * sizeof(float)));
+    IPDM_HIP_CHECK(hipMemcpy(d_w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (b_host) {
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_b, Cout * sizeof(float)));
+        IPDM_HIP_CHECK(hipMemcpy(d_b, b_host, Cout * sizeof(float), hipMemcpyHostToDevice));
+    }
+    int rc = IPDM_OK;
+    if (act) {
+        IPDM_REQUIRE(gamma_host && beta_host && groups > 0, "op_conv2d: GN prologue needs gamma/beta/groups");
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_g, Cin * sizeof(float)));
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_be, Cin * sizeof(float)));
+        IPDM_HIP_CHECK(hipMemcpy(d_g, gamma_host, Cin * sizeof(float), hipMemcpyHostToDevice));
+        IPDM_HIP_CHECK(hipMemcpy(d_be, beta_host, Cin * sizeof(float), hipMemcpyHostToDevice));
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_sc, (size_t)B * Cin * sizeof(float)));
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_sh, (size_t)B * Cin * sizeof(float)));
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_part, gn_partials_bytes(B, groups)));
+        GnArgs g;
+        g.x1 = d_x1; g.x2 = d_x2; g.C1 = C1; g.C2 = C2; g.B = B; g.HW = (long)Hs * Ws; g.groups = groups;
+        g.gamma = d_g; g.beta = d_be; g.eps = 1e-5f; g.partials = d_part; g.scale = d_sc; g.shift = d_sh;
+        rc = gn_stats_launch(g, st);
+    }
+    if (!rc) {
+        const int pad = ksize / 2;
+        ConvArgs a;
+        a.x1 = d_x1; a.x2 = d_x2; a.C1 = C1; a.C2 = C2; a.B = B; a.Hs = Hs; a.Ws = Ws; a.H = H; a.W = W;
+        a.upsample = (H != Hs || W != Ws);
+        a.scale_y = (float)Hs / (float)H; a.scale_x = (float)Ws / (float)W;
+        a.w = d_w; a.cout_pad = cout_pad; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
+        a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
+        a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
+        a.tiles_x = a.tiles_y = a.co_tiles = 0;
+        rc = conv2d_launch(a, st);
+    }
+    IPDM_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_g); (void)hipFree(d_be); (void)hipFree(d_sc); (void)hipFree(d_sh);
+    (void)hipFree(d_part);
+    return rc;
+}

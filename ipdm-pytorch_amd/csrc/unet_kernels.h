@@ -1,0 +1,55 @@
+// Internal (non-ABI) interfaces between the UNet executor and its kernels.
+#pragma once
+#include <vector>
+#include "common.h"
+
+namespace ipdm {
+
+struct ConvArgs {
+    const float *x1, *x2;        // sources [B,C1,Hs,Ws], [B,C2,Hs,Ws] (x2 may be null)
+    int C1, C2, B;
+    int Hs, Ws;                  // source spatial size
+    int H, W;                    // (virtual) conv-input size; != (Hs,Ws) => nearest up-sampling
+    int upsample;
+    float scale_y, scale_x;      // Hs/H, Ws/W in float32 (ATen's nearest rule)
+    const float *w;              // packed [Cin_pad][k*k][cout_pad]
+    int cout_pad;
+    const float *bias;           // [Cout] or null
+    int Cout, ksize, stride;
+    int Ho, Wo;
+    int act;                     // 0 none, 1 GroupNorm, 2 GroupNorm+SiLU (prologue on the input)
+    const float *gn_scale, *gn_shift;   // [B, C1+C2]
+    const float *res;            // [B,Cout,Ho,Wo] or null
+    float *out;
+    int tiles_x, tiles_y, co_tiles;     // filled by the launcher
+};
+
+int conv2d_launch(const ConvArgs &a, hipStream_t st);
+void conv_pack_weights(const float *w, int Cout, int Cin, int ks, std::vector<float> &packed, int &cin_pad, int &cout_pad);
+
+// GroupNorm statistics over (possibly concatenated) NCHW sources -> per-(sample,channel) affine
+// scale/shift: y = x*scale + shift == gamma*(x-mean)*rstd + beta.
+struct GnArgs {
+    const float *x1, *x2;
+    int C1, C2, B;
+    long HW;
+    int groups;
+    const float *gamma, *beta;   // [C1+C2]
+    float eps;
+    double *partials;            // [B, groups, GN_SPLIT, 2]
+    float *scale, *shift;        // [B, C1+C2]
+};
+constexpr int GN_SPLIT = 32;
+size_t gn_partials_bytes(int B, int groups);
+int gn_stats_launch(const GnArgs &a, hipStream_t st);
+
+int attention_launch(const float *qkv, float *out, int B, int heads, int d, int T, hipStream_t st);
+
+// time embedding: emb = Linear(SiLU(Linear(sinusoid(t)))) ; out = SiLU(emb)  (Model/model.py:14-32,218-222,105-108)
+int temb_launch(const float *freqs, int mc, int t, const float *w0, const float *b0, const float *w2, const float *b2,
+                float *tmp, float *silu_emb, hipStream_t st);
+// y[r] = base[r] + dot(W[r,:], v) + b[r]  for r < rows, K columns
+int gemv_bias_launch(const float *W, const float *b, const float *base, const float *v, float *y, int rows, int K,
+                     hipStream_t st);
+
+}  // namespace ipdm

@@ -1,0 +1,40 @@
+"""Case definitions shared by tests/golden/make_golden.py (reference side) and the tests (oracle /
+HIP side).  Data only."""
+import torch
+
+from ipdm_pytorch_amd import synth
+
+SMALL_CFGS = {
+    "a": dict(in_channels=1, model_channels=16, out_channels=1, num_res_blocks=2, attention_resolutions=(2, 4),
+              channel_mult=(1, 1, 2, 4), num_heads=1),
+    "b": dict(in_channels=1, model_channels=48, out_channels=1, num_res_blocks=1, attention_resolutions=(4,),
+              channel_mult=(0.25, 0.5, 0.75, 4 / 3), num_heads=1),
+    "c": dict(in_channels=1, model_channels=8, out_channels=1, num_res_blocks=1, attention_resolutions=(1, 2),
+              channel_mult=(1, 2, 4), num_heads=4),
+}
+SMALL_SHAPES = {"a": (2, 1, 24, 20), "b": (1, 1, 23, 19), "c": (1, 1, 12, 10)}
+
+LOOP_CFG = dict(in_channels=1, model_channels=16, out_channels=1, num_res_blocks=1, attention_resolutions=(4,),
+                channel_mult=(1, 1, 2, 4), num_heads=1)
+LOOP_CASES = {
+    "img_const": ("img", (1, 1, 32, 32), 1, dict(t_start=[3, 2], clip=True, lambda_ratio=10, eta=0.7,
+                                                 constant_guidance=0.45)),
+    "img_adapt": ("img", (1, 1, 32, 32), 1, dict(t_start=[3, 3], clip=True, lambda_ratio=10, eta=0.7,
+                                                 constant_guidance=None)),
+    "proj_adapt": ("proj", (1, 1, 40, 24), 5, dict(t_start=[3, 3, 2], clip=False, lambda_ratio=1, eta=0.5,
+                                                   constant_guidance=None)),
+    "proj_const": ("proj", (1, 1, 40, 24), 5, dict(t_start=[2, 2], clip=True, lambda_ratio=1, eta=0.5,
+                                                   constant_guidance=0.3)),
+}
+
+
+class noise_feed:
+    """Hashed N(0,1) draws in call order: draw k of feed `seed` = hash_normal(shape, seed*1000+k)."""
+
+    def __init__(self, seed, shape):
+        self.seed, self.shape, self.count = seed, tuple(shape), 0
+
+    def __call__(self):
+        z = torch.from_numpy(synth.hash_normal(self.shape, self.seed * 1000 + self.count))
+        self.count += 1
+        return z
