@@ -25,13 +25,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int D = 64;          // head dim (C/heads); the reference configs all have 256/4
 constexpr int KV = 64;         // keys per LDS tile
 constexpr int KP = KV;         // K pitch  [c][s]
 constexpr int VP = KV + 1;     // V pitch  [c][s], odd -> conflict-free column reads
 
 __device__ inline int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+template <int D>   // head dim C/heads: 64 in both reference configs (256/4); 32 for reduced test nets
 __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restrict__ qkv, float *__restrict__ out,
                                                            int heads, int T, float scale)
 {
@@ -53,9 +53,10 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
 #pragma unroll
     for (int p = 0; p < D / 2; ++p) qreg[p] = tvalid ? qp[(size_t)(2 * p + lh) * T + t] * scale : 0.0f;
 
-    f32x16 o[2];
+    constexpr int CB = D / 32;
+    f32x16 o[CB];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[cb][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
             l_run = l_run * alpha + rs;
             m_run = m_new;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+            for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
             // ---- O[c, t] += sum_s V[c, s] P[s, t]; accumulator register r of P is the k-pair
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
             for (int r = 0; r < 16; ++r) {
                 const int s = sb * 32 + crow(r, lh);
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
+                for (int cb = 0; cb < CB; ++cb) {
                     const float av = v_lds[(cb * 32 + l31) * VP + s];      // A[i=channel][k=key]
                     o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sacc[r], o[cb], 0, 0, 0);
                 }
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
         const float inv = 1.0f / l_run;
         float *op = out + ((size_t)b * heads * D + (size_t)head * D) * T;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = cb * 32 + crow(r, lh);
@@ -141,11 +142,12 @@ namespace ipdm {
 int attention_launch(const float *qkv, float *out, int B, int heads, int d, int T, hipStream_t st)
 {
     IPDM_REQUIRE(qkv && out && B > 0 && heads > 0 && T > 0, "attention: bad argument");
-    if (d != D) { set_error("attention: head dim %d unsupported (kernel is specialised for %d)", d, D); return IPDM_ERR_UNSUPPORTED; }
+    if (d != 64 && d != 32) { set_error("attention: head dim %d unsupported (kernel is specialised for 64 and 32)", d); return IPDM_ERR_UNSUPPORTED; }
     // scale = 1/sqrt(sqrt(C/heads)) (Model/model.py:149); python double -> f32 scalar
     const float scale = (float)(1.0 / sqrt(sqrt((double)d)));
     dim3 grid(cdiv(T, 128), B * heads);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, heads, T, scale);
+    if (d == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, st, qkv, out, heads, T, scale);
+    else hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, st, qkv, out, heads, T, scale);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }

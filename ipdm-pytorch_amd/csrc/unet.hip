@@ -479,7 +479,7 @@ extern "C" int ipdm_unet_create(const ipdm_unet_cfg *cfg, const float *const *we
                 if ((r = make_norm(net, wm, p + ".norm", l.cin, ap.n))) break;
                 if ((r = make_conv(net, wm, p + ".qkv.weight", "", 3 * l.cin, l.cin, 1, ap.qkv))) break;
                 r = make_conv(net, wm, p + ".proj.weight", p + ".proj.bias", l.cin, l.cin, 1, ap.proj);
-                if (!r && l.cin / cfg->num_heads != 64) { set_error("unet_create: attention head dim %d unsupported (64 only)", l.cin / cfg->num_heads); r = IPDM_ERR_UNSUPPORTED; }
+                if (!r && l.cin / cfg->num_heads != 64 && l.cin / cfg->num_heads != 32) { set_error("unet_create: attention head dim %d unsupported (64 or 32)", l.cin / cfg->num_heads); r = IPDM_ERR_UNSUPPORTED; }
                 break;
             }
         }

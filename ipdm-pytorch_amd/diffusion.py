@@ -1,0 +1,243 @@
+"""GaussianDiffusion: host-side mirror of the reference's Model/model.py:376-642 on the dense
+sampling path.  Control flow (passes, steps, guidance scheduling) is Python as in the reference;
+every tensor operation is a libipdm_hip.so call on device-resident buffers -- nothing goes through
+the host inside the loop (the reference does a D2H/np.vectorize/numba/H2D round trip per step in
+adaptive mode, Model/model.py:554-560).
+
+Semantics differences, by design: all statistics (`std`, `median`) are per slice, i.e.
+a batch of B slices gives exactly what the reference gives when called B times with B=1.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call, lib, ptr
+
+# np.polyfit coefficients of the guidance curves (Utils/train_test_utils.py:842-865), highest power
+# first; values as produced by the reference (tests/golden/misc.npz holds the same numbers).
+CURVE_COEFFS = {
+    "img": ([170.45454545463878, -857.3232323237245, 1588.825757576721, -1314.8304473312783, 432.87337662364365],
+            [0.7496994267099147, -4.199781115690005, 5.908637798542919]),
+    "proj": ([-71.02272727288062, 417.6136363644583, -893.418560607694, 800.875270564197, -234.09496753293],
+             [2.3612714971236124, -14.22455278875205, 21.070551037502682]),
+}
+
+
+def _stream():
+    return _lib.current_stream()
+
+
+def cosine_lambda(ts, power, i):
+    """cosine_beta_schedule(ts, schedule_power=power)[i] (Model/model.py:546,552) as a python float."""
+    out = C.c_double()
+    call("ipdm_cosine_lambda", int(ts), float(power), int(i), C.byref(out))
+    return out.value
+
+
+class NoiseSource:
+    """Counter-based N(0,1) source replacing torch.randn_like (Model/model.py:440,509).
+
+    Draw k of global slice s is a pure function of (seed, s, k): the same slice gets the same noise
+    whatever the batch composition or the number of GPUs (shard invariance).  `slice_id0` is the
+    global index of the first slice of the local batch."""
+
+    def __init__(self, seed=0, slice_id0=0):
+        self.seed, self.slice_id0, self.draw = int(seed), int(slice_id0), 0
+
+    def next_like(self, x):
+        out = torch.empty_like(x)
+        B = x.shape[0]
+        call("ipdm_randn", ptr(out), B, x.numel() // B, self.seed, self.slice_id0, self.draw, _stream())
+        self.draw += 1
+        return out
+
+
+class InjectedNoise:
+    """Parity mode: hands out caller-supplied draws (an iterable of tensors shaped like x) in order."""
+
+    def __init__(self, draws):
+        self._it = iter(draws)
+        self.draw = 0
+
+    def next_like(self, x):
+        z = next(self._it).to(x.device, torch.float32).contiguous()
+        assert z.shape == x.shape, "injected noise shape %s != %s" % (tuple(z.shape), tuple(x.shape))
+        self.draw += 1
+        return z
+
+
+class GaussianDiffusion:
+    """Mirror of Model/model.py:376-642 (cosine schedule only -- the only one the harness builds,
+    Utils/train_test_utils.py:221-223,243-245)."""
+
+    def __init__(self, timesteps=1000, beta_schedule="cosine", schedule_power=1):
+        if beta_schedule != "cosine":
+            raise NotImplementedError("only the cosine schedule is on the reference's sampling path")
+        self.timesteps = timesteps
+        self.schedule_power = schedule_power
+        h = C.c_void_p()
+        call("ipdm_schedule_create", int(timesteps), float(schedule_power), C.byref(h))
+        self._h = h
+        self._ws = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None:
+                lib().ipdm_schedule_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def coeffs(self, t):
+        """(sqrt_ac, sqrt_1m_ac, sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, log_var, var) at t, float32
+        (_extract, Model/model.py:424-428)."""
+        out = (C.c_float * 8)()
+        call("ipdm_schedule_coeffs", self._h, int(t), C.byref(out))
+        return tuple(out)
+
+    def _workspace(self, key, nbytes, device):
+        w = self._ws.get((key, device))
+        if w is None or w.numel() < nbytes:
+            w = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            self._ws[(key, device)] = w
+        return w
+
+    # ---- Model/model.py:438-445
+    def q_sample(self, x_start, t, noise):
+        x = x_start.contiguous()
+        out = torch.empty_like(x)
+        call("ipdm_q_sample", self._h, int(t), ptr(x), ptr(noise), ptr(out), x.numel(), _stream())
+        return out
+
+    # ---- Model/model.py:492-515 (per-slice statistics)
+    def p_sample_condition(self, model, x_t, x_0, t, clip_denoised=True, lambda_=1.0, noise=None, eps_pred=None):
+        """One guided reverse step.  `lambda_` is a python float or a small [B,1,mh,mw] map (nearest-
+        upsampled inside the kernel).  `noise`: the N(0,1) draw (a tensor)."""
+        B, _, H, W = x_t.shape
+        x_t = x_t.contiguous()
+        if eps_pred is None:
+            eps_pred = model(x_t, int(t))
+        ws = self._workspace("step", lib().ipdm_ddpm_workspace_bytes(B), x_t.device)
+        out = torch.empty_like(x_t)
+        if isinstance(lambda_, torch.Tensor) and lambda_.dim() > 0:
+            lm = lambda_.to(x_t.device, torch.float32).contiguous()
+            mh, mw = lm.shape[-2], lm.shape[-1]
+            call("ipdm_ddpm_step", self._h, int(t), ptr(eps_pred), ptr(x_t), ptr(x_0), ptr(noise), ptr(out), B, H, W,
+                 0.0, ptr(lm), mh, mw, 1 if clip_denoised else 0, ptr(ws), ws.numel(), _stream())
+        else:
+            call("ipdm_ddpm_step", self._h, int(t), ptr(eps_pred), ptr(x_t), ptr(x_0), ptr(noise), ptr(out), B, H, W,
+                 float(lambda_), None, 0, 0, 1 if clip_denoised else 0, ptr(ws), ws.numel(), _stream())
+        return out
+
+    # ---- guidance map after pass 0 (Model/model.py:574-614)
+    def guidance_map(self, x, img, mode, kernel_size, amplitude):
+        """Returns (Lambda [B,1,H/k,W/k] f32 -- the curve output, expmax [B] f32)."""
+        B, _, H, W = x.shape
+        ks = int(kernel_size)
+        Lam = torch.empty((B, 1, H // ks, W // ks), dtype=torch.float32, device=x.device)
+        emax = torch.empty((B,), dtype=torch.float32, device=x.device)
+        ws = self._workspace("guid", lib().ipdm_guidance_workspace_bytes(B, H, W), x.device)
+        p1, p2 = CURVE_COEFFS[mode]
+        a1 = (C.c_double * 5)(*p1)
+        a2 = (C.c_double * 3)(*p2)
+        call("ipdm_guidance_map", ptr(x.contiguous()), ptr(img.contiguous()), ptr(Lam), ptr(emax), B, H, W, ks,
+             float(amplitude), 0 if mode == "img" else 1, a1, a2, ptr(ws), ws.numel(), _stream())
+        return Lam, emax
+
+    def lambda_ratio(self, Lam, i, ts):
+        """condition_lambda_ratio_cuda + clip (Model/model.py:328-351,558) on the small map."""
+        out = torch.empty_like(Lam)
+        call("ipdm_lambda_ratio", ptr(Lam), ptr(out), Lam.numel(), int(i), int(ts), _stream())
+        return out
+
+    # ---- Model/model.py:517-642
+    @torch.no_grad()
+    def guided_reverse_process(self, model, img, t_start=None, clip=True, lambda_ratio=1, eta=0.5, save_states=False,
+                               mode="img", constant_guidance=None, noise=None, **kwargs):
+        """Same signature and return value as the reference: (list of iterates, reverse states,
+        noise_strength).  Extra keyword: `noise` = NoiseSource / InjectedNoise (default: NoiseSource(0))."""
+        if kwargs.get("only_convertor"):
+            return [img], None, None
+        if kwargs.get("normal"):
+            raise NotImplementedError("opt.normal (Yeo-Johnson) is off in every shipped config (SURVEY.md section 2)")
+        noise = noise if noise is not None else NoiseSource(0)
+        img = img.to(torch.float32).contiguous()
+        B = img.shape[0]
+        n = img.numel()
+        x = img.clone()
+        guide = img.clone()
+        iters_out, reverse_states = [], []
+        adaptive = t_start is None
+        t_list = [20] if adaptive else list(t_start)
+        noise_strength = None
+        it = 0
+        Lam = None
+        ldct = kwargs.get("ldct")
+        while t_list:
+            ts = t_list.pop(0)
+            x = self.q_sample(x, ts, noise.next_like(x))
+            for i in reversed(range(ts)):
+                if constant_guidance is None:
+                    if it == 0:
+                        l_s = cosine_lambda(ts, lambda_ratio, i)
+                    else:
+                        l_s = self.lambda_ratio(Lam, i, ts)
+                else:
+                    l_s = constant_guidance
+                x = self.p_sample_condition(model, x, guide, i, clip_denoised=clip, lambda_=l_s,
+                                            noise=noise.next_like(x))
+                if save_states:
+                    reverse_states.append(x.detach().cpu().numpy())
+            if clip:
+                y = torch.empty_like(x)
+                call("ipdm_clamp", ptr(x), ptr(y), n, 0 if mode == "img" else 1, _stream())
+                x = y
+            if it == 0 and constant_guidance is None:
+                if mode == "img":
+                    Lam, emax = self.guidance_map(x, img, "img", kwargs["kernel_size_img"], kwargs["amplitude_img"])
+                    if adaptive:
+                        ns = kwargs.get("noise_strength")
+                        if ns == "high":
+                            t_list, eta = [15, 15, 15], 0.6
+                        elif ns == "mid":
+                            t_list, eta = [15, 12, 10], 0.55
+                        else:
+                            t_list, eta = [10, 10, 10], 0.5
+                else:
+                    Lam, emax = self.guidance_map(x, img, "proj", kwargs["kernel_size_proj"], kwargs["amplitude_proj"])
+                    if adaptive:
+                        m = float(emax.max().item())       # the one device->host scalar of adaptive mode
+                        if m >= 30:
+                            t_list, noise_strength, eta = [30, 25, 20], "high", 0.6
+                        elif m >= 4.5:
+                            t_list, noise_strength, eta = [20, 18, 15], "mid", 0.5
+                        else:
+                            t_list, noise_strength, eta = [15, 15, 15], "low", 0.5
+            iters_out.append(x)
+            if constant_guidance is None:
+                if it >= 1:
+                    guide = self._guide_update(mode, eta, x, img, ldct)
+                if it == 0:
+                    x = img.clone()
+            else:
+                guide = self._guide_update(mode, eta, x, img, ldct)
+            it += 1
+        if len(iters_out) > 1:
+            avg = torch.empty_like(iters_out[-1])
+            call("ipdm_axpbypcz", ptr(iters_out[-1]), ptr(iters_out[-2]), None, ptr(avg), n, 0.5, 0.5, 0.0, _stream())
+            iters_out.append(avg)
+        if adaptive:
+            return iters_out[1:], reverse_states, noise_strength
+        return iters_out, reverse_states, noise_strength
+
+    def _guide_update(self, mode, eta, x, img, ldct):
+        """Model/model.py:625-635."""
+        out = torch.empty_like(x)
+        if mode == "proj":
+            call("ipdm_axpbypcz", ptr(x), ptr(img), None, ptr(out), x.numel(), float(eta), float(1 - eta), 0.0, _stream())
+        else:
+            ld = ldct.to(x.device, torch.float32).contiguous()
+            call("ipdm_axpbypcz", ptr(x), ptr(img), ptr(ld), ptr(out), x.numel(), float(eta), float(0.95 - eta), 0.05,
+                 _stream())
+        return out

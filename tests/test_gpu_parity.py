@@ -1,0 +1,455 @@
+"""GPU parity tests: the HIP path (through the C ABI of libipdm_hip.so) against the CPU oracle and
+the golden vectors of the imported reference.  Tolerances are absolute unless noted and written
+next to each check; north_star: 1e-5 max-abs on the FBP index map, 1e-4 relative PSNR end to end."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import diffusion as od   # noqa: E402
+from oracle import fbp as of         # noqa: E402
+from oracle import unet as ou        # noqa: E402
+from ipdm_pytorch_amd import synth   # noqa: E402
+from tests.golden.cases import SMALL_CFGS, SMALL_SHAPES, LOOP_CFG, LOOP_CASES, noise_feed  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _dev(a):
+    return torch.as_tensor(a).to(DEV)
+
+
+# =========================================================================== FBP
+@pytest.fixture(scope="module")
+def fbp():
+    from ipdm_pytorch_amd.fbp import FBP
+    return FBP(DEV)
+
+
+def test_fbp_tables_match_reference_geometry(fbp, golden):
+    g = golden("fbp")
+    np.testing.assert_array_equal(fbp.table(0)[::97], g["theta"])
+    np.testing.assert_array_equal(fbp.table(3)[::57], g["nda"])
+    np.testing.assert_array_equal(fbp.table(4)[::101], g["h_RL"])
+    np.testing.assert_array_equal(fbp.table(4)[905:918], g["h_RL_center"])
+    np.testing.assert_array_equal(fbp.table(2)[::4099], g["r"])
+    assert np.abs(fbp.table(1)[::4099] - g["phi"]).max() < 1e-15 * 7     # libm atan vs numpy: <= 1 ulp
+    assert np.abs(fbp.table(5)[::57] - g["weight"]).max() <= 8e-6        # cosf vs np.cos(f32): 1 ulp of ~59
+
+
+def test_fbp_ramp_rows_golden(fbp, golden):
+    g = golden("fbp")
+    rows = (synth.hash_uniform((1, 6, 912), 51) * 4.0).astype(np.float32)
+    # the plan has 2000 views; filter a [1,2000,912] sinogram whose first 6 rows are the golden rows.
+    # golden rows went through conv_pj directly (no flip/weight) -> undo weight with flip=False path:
+    sino = np.zeros((1, 2000, 912), dtype=np.float32)
+    sino[0, :6] = rows
+    geo = of.FBPGeometry()
+    got = fbp.filter_device(_dev(sino), flip=False).cpu().numpy()[0, :6]
+    want = of.ramp_filter(_geo_views(geo, 6), of.weight_sinogram(geo, rows, flip=False))[0]
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-6 * scale
+
+
+def _geo_views(geo, n):
+    import copy
+    g2 = copy.copy(geo)
+    g2.n_views = n
+    return g2
+
+
+def test_fbp_filter_full(fbp):
+    geo = of.FBPGeometry()
+    sino = (synth.hash_uniform((2, 2000, 912), 71) * 6.0).astype(np.float32)
+    got = fbp.filter_device(_dev(sino), flip=True).cpu().numpy()
+    want = of.ramp_filter(geo, of.weight_sinogram(geo, sino, flip=True))
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+
+
+def test_fbp_index_map(fbp, golden):
+    """north_star: <= 1e-5 max-abs on the FBP index map (detector coordinate u)."""
+    g = golden("fbp")
+    geo = of.FBPGeometry()
+    rng = np.random.default_rng(5)
+    pix = np.concatenate([g["bp_pixels"], rng.integers(0, 512 * 512, 500).astype(np.int32)])
+    u_dev = fbp.index_map(pix).cpu().numpy()
+    _, u_ref = of.backproject(geo, np.zeros((1, 2000, 912), np.float32), pixels=pix, want_umap=True)
+    assert np.abs(u_dev - u_ref).max() < 1e-9
+    assert np.abs(u_dev[::100, :12] - g["bp_umap"]).max() < 1e-9        # reference's own expression
+    assert np.array_equal(np.floor(u_dev), np.floor(u_ref)) or (np.floor(u_dev) != np.floor(u_ref)).mean() < 1e-6
+
+
+def test_fbp_backprojection_full_image(fbp, golden):
+    g = golden("fbp")
+    geo = of.FBPGeometry()
+    filt = (synth.hash_uniform((1, 2000, 912), 52) - 0.5).astype(np.float32)
+    got = fbp.backproject_device(_dev(filt)).cpu().numpy()
+    want = of.backproject(geo, filt)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-6 * scale
+    # the reference's own sequential loop on scattered pixels
+    assert np.abs(got.reshape(-1)[g["bp_pixels"]] - g["bp_values"]).max() <= 2e-6 * scale
+
+
+def test_fbp_convert_phantom_batch(fbp, golden):
+    g = golden("fbp")
+    sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(3)), seed=3)
+    batch = np.stack([sino, sino * 0.5, sino[::-1].copy()])          # ragged batch of 3 (KB=2 + KB=1 launches)
+    got = fbp.convert_device(_dev(batch)).cpu().numpy()
+    scale = np.abs(g["convert_rows"]).max()
+    assert np.abs(got[0, ::8, ::8] - g["convert_sub8"]).max() <= 5e-6 * scale
+    assert np.abs(got[0, 250:254] - g["convert_rows"]).max() <= 5e-6 * scale
+    # linearity (size-independent property): FBP(0.5 s) == 0.5 FBP(s) exactly (power-of-two scaling)
+    np.testing.assert_array_equal(got[1], 0.5 * got[0])
+    want2 = of.convert(of.FBPGeometry(), batch[2:3])
+    assert np.abs(got[2] - want2[0]).max() <= 5e-6 * np.abs(want2).max()
+    # reference return type: Tensor in -> CPU Tensor out
+    out = fbp.convert(torch.from_numpy(sino))
+    assert isinstance(out, torch.Tensor) and out.device.type == "cpu" and tuple(out.shape) == (1, 512, 512)
+
+
+def test_sharpen(golden):
+    from ipdm_pytorch_amd.fbp import tensor_sharpen
+    g = golden("misc")
+    img = torch.from_numpy(synth.hash_uniform((1, 1, 17, 13), 61))
+    for n in (42, 70):
+        got = tensor_sharpen(img.to(DEV), n).cpu().numpy()
+        np.testing.assert_allclose(got, g["sharpen_%d" % n], rtol=0, atol=1e-6)
+    assert tensor_sharpen(img.to(DEV), -1).data_ptr() != 0
+
+
+# =========================================================================== diffusion arithmetic
+@pytest.fixture(scope="module")
+def gd5():
+    from ipdm_pytorch_amd.diffusion import GaussianDiffusion
+    return GaussianDiffusion(1000, "cosine", 5)
+
+
+def test_schedule_tables_golden(golden):
+    from ipdm_pytorch_amd.diffusion import GaussianDiffusion, cosine_lambda
+    g = golden("schedule")
+    for p in (1, 5):
+        gd = GaussianDiffusion(1000, "cosine", p)
+        tab = np.array([gd.coeffs(t) for t in range(30)], dtype=np.float32).T
+        # float64 tables computed with libm instead of torch: identical after the cast except for rare 1-ulp flips
+        np.testing.assert_allclose(tab, g["tables_p%d" % p], rtol=2e-7, atol=0)
+    for ts, power in ((15, 1), (15, 10), (5, 10), (20, 1)):
+        got = np.array([cosine_lambda(ts, power, i) for i in range(ts)])
+        np.testing.assert_allclose(got, g["lambda_ts%d_p%d" % (ts, power)], rtol=1e-13, atol=0)
+
+
+def test_single_step_golden(gd5, golden):
+    g = golden("step")
+    shape = (1, 1, 16, 12)
+    x_t = torch.from_numpy(synth.hash_normal(shape, 31)) * 0.3 + 0.5
+    x_0 = torch.from_numpy(synth.hash_normal(shape, 32)) * 0.2 + 0.5
+    pred = torch.from_numpy(synth.hash_normal(shape, 33)) * 1.7 + 0.1
+    lam_small = torch.from_numpy(synth.hash_uniform((1, 1, 4, 3), 34)) * 0.9 + 0.05
+    noise = torch.from_numpy(synth.hash_normal(shape, 35 * 1000))
+    cases = {"scalar_t7": (7, 0.45, True), "scalar_t0": (0, 0.45, True),
+             "tensor0d_t5": (5, float(od.cosine_beta_schedule(15, schedule_power=1)[5]), False),
+             "map_t3": (3, lam_small.to(DEV), False)}
+    for tag, (t, lam, clip) in cases.items():
+        got = gd5.p_sample_condition(None, x_t.to(DEV), x_0.to(DEV), t, clip_denoised=clip, lambda_=lam,
+                                     noise=noise.to(DEV), eps_pred=pred.to(DEV)).cpu().numpy()
+        np.testing.assert_allclose(got, g[tag], rtol=0, atol=2e-6)
+
+
+def test_step_full_size_per_slice(gd5):
+    """B=3 sinogram-sized slices: slice b must equal the oracle run on that slice alone."""
+    shape = (3, 1, 2000, 912)
+    x_t = torch.from_numpy(synth.hash_normal(shape, 81)) * 0.4 + 1.5
+    x_0 = torch.from_numpy(synth.hash_normal(shape, 82)) * 0.3 + 1.5
+    pred = torch.from_numpy(synth.hash_normal(shape, 83)) * torch.tensor([1.0, 2.5, 0.3]).view(3, 1, 1, 1) + 0.2
+    noise = torch.from_numpy(synth.hash_normal(shape, 84))
+    lam_small = torch.from_numpy(synth.hash_uniform((3, 1, 500, 228), 85)) * 0.9 + 0.05
+    sch = od.Schedule(1000, 5)
+    for lam_dev, lam_cpu in ((0.37, 0.37), (lam_small.to(DEV), lam_small)):
+        got = gd5.p_sample_condition(None, x_t.to(DEV), x_0.to(DEV), 9, clip_denoised=False, lambda_=lam_dev,
+                                     noise=noise.to(DEV), eps_pred=pred.to(DEV)).cpu()
+        for b in range(3):
+            lam_b = lam_cpu if not isinstance(lam_cpu, torch.Tensor) else \
+                torch.nn.functional.interpolate(lam_cpu[b:b + 1], size=(2000, 912), mode="nearest")
+            want = od.p_sample_condition(sch, lambda x, t: pred[b:b + 1], x_t[b:b + 1], x_0[b:b + 1], 9, lam_b, False,
+                                         noise[b:b + 1])
+            assert (got[b:b + 1] - want).abs().max() <= 5e-6 * want.abs().max()
+
+
+def test_q_sample_and_elementwise(gd5):
+    from ipdm_pytorch_amd import _lib
+    shape = (2, 1, 64, 48)
+    x = torch.from_numpy(synth.hash_normal(shape, 91))
+    z = torch.from_numpy(synth.hash_normal(shape, 92))
+    sch = od.Schedule(1000, 5)
+    got = gd5.q_sample(x.to(DEV), 15, z.to(DEV)).cpu()
+    want = od.q_sample(sch, x, 15, z)
+    assert (got - want).abs().max() <= 1e-6
+    y = torch.empty_like(x, device=DEV)
+    for mode in (0, 1):
+        _lib.call("ipdm_clamp", _lib.ptr(x.to(DEV)), _lib.ptr(y), x.numel(), mode, _lib.current_stream())
+        want = x.clamp(0, 1) if mode == 0 else x.clamp(min=0)
+        assert torch.equal(y.cpu(), want)
+
+
+def test_randn_statistics_and_shard_invariance():
+    from ipdm_pytorch_amd.diffusion import NoiseSource
+    x = torch.empty((4, 1, 512, 512), device=DEV)
+    a = NoiseSource(seed=7, slice_id0=0).next_like(x)
+    b = NoiseSource(seed=7, slice_id0=2).next_like(x[:2])
+    assert torch.equal(a[2:], b)                         # slice 2,3 identical whichever shard generates them
+    s2 = NoiseSource(seed=7, slice_id0=0)
+    s2.next_like(x)
+    c = s2.next_like(x)
+    assert not torch.equal(a, c)                          # next draw differs
+    v = a.double().cpu().numpy().reshape(4, -1)
+    assert np.abs(v.mean(axis=1)).max() < 0.01 and np.abs(v.std(axis=1) - 1).max() < 0.01
+    assert abs(np.corrcoef(v[0], v[1])[0, 1]) < 0.01
+    k = ((v ** 4).mean() / (v ** 2).mean() ** 2)
+    assert abs(k - 3.0) < 0.05                            # kurtosis of a Gaussian
+    odd = torch.empty((1, 1, 7, 5), device=DEV)
+    assert torch.isfinite(NoiseSource(1).next_like(odd)).all()
+
+
+def test_slice_median():
+    from ipdm_pytorch_amd import _lib
+    for n in (1, 2, 7, 1000, 1824000, 262144):
+        x = torch.from_numpy(synth.hash_normal((3, n), 100 + n % 97))
+        if n > 100:
+            x[1, : n // 2] = 0.25      # heavy ties
+            x[2] = -x[2].abs()
+        xd = x.to(DEV)
+        med = torch.empty(3, device=DEV)
+        ws = torch.empty(1 << 16, dtype=torch.uint8, device=DEV)
+        _lib.call("ipdm_slice_median", _lib.ptr(xd), _lib.ptr(med), 3, n, _lib.ptr(ws), ws.numel(), _lib.current_stream())
+        want = torch.stack([torch.median(x[b]) for b in range(3)])
+        assert torch.equal(med.cpu(), want), (n, med.cpu(), want)
+
+
+def test_guidance_map_and_lambda_ratio(gd5):
+    for mode, shape, amp in (("proj", (2, 1, 2000, 912), 7.0), ("img", (2, 1, 512, 512), 30.0),
+                             ("proj", (1, 1, 40, 24), 7.0)):
+        if mode == "proj":
+            img = torch.from_numpy(synth.hash_uniform(shape, 111)) * 4.0
+            x = img + torch.from_numpy(synth.hash_normal(shape, 112)) * 0.08
+        else:
+            img = torch.from_numpy(synth.hash_uniform(shape, 113)) * 0.05 + 0.17
+            x = img + torch.from_numpy(synth.hash_normal(shape, 114)) * 0.004
+        Lam, emax = gd5.guidance_map(x.to(DEV), img.to(DEV), mode, 4, amp)
+        for b in range(shape[0]):
+            e, want = od.delta_map(x[b:b + 1], img[b:b + 1], mode, 4, amp)
+            # exp(amp*delta) amplifies the 1e-7 pooling differences; the curve has slope up to ~40
+            assert (Lam[b:b + 1].cpu() - want).abs().max() <= 2e-4, (mode, b)
+            assert abs(float(emax[b]) - float(e.max())) <= 1e-5 * float(e.max())
+        for (i, ts) in ((14, 15), (0, 15), (2, 3)):
+            got = gd5.lambda_ratio(Lam, i, ts).cpu()
+            want = od.lambda_ratio_map(Lam.cpu(), i, ts)
+            assert (got - want).abs().max() <= 1e-6
+
+
+# =========================================================================== conv / attention kernels
+def _conv_case(B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res, seed):
+    from ipdm_pytorch_amd import _lib
+    import torch.nn.functional as F
+    Cin = C1 + C2
+    x1 = torch.from_numpy(synth.hash_normal((B, C1, Hs, Ws), seed))
+    x2 = torch.from_numpy(synth.hash_normal((B, C2, Hs, Ws), seed + 1)) * 2 + 0.5 if C2 else None
+    w = torch.from_numpy(synth.hash_normal((Cout, Cin, ks, ks), seed + 2)) / np.sqrt(Cin * ks * ks)
+    bias = torch.from_numpy(synth.hash_normal((Cout,), seed + 3))
+    gamma = torch.from_numpy(synth.hash_uniform((Cin,), seed + 4)) + 0.5
+    beta = torch.from_numpy(synth.hash_normal((Cin,), seed + 5)) * 0.2
+    groups = ou.gn_groups(Cin)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    h = xin
+    if act:
+        h = F.group_norm(h, groups, gamma, beta, eps=1e-5)
+        if act == 2:
+            h = F.silu(h)
+    if (H, W) != (Hs, Ws):
+        h = F.interpolate(h, size=(H, W), mode="nearest")
+    want = F.conv2d(h, w, bias, stride=stride, padding=ks // 2)
+    r = torch.from_numpy(synth.hash_normal(tuple(want.shape), seed + 6)) if res else None
+    if res:
+        want = want + r
+    out = torch.empty(tuple(want.shape), device=DEV)
+    x1d = x1.to(DEV)
+    x2d = x2.to(DEV) if x2 is not None else None
+    rd = r.to(DEV) if res else None
+    wn, bn, gn_, ben = (np.ascontiguousarray(t.numpy()) for t in (w, bias, gamma, beta))
+    _lib.call("ipdm_op_conv2d", _lib.ptr(x1d), C1, _lib.ptr(x2d), C2, B, Hs, Ws, H, W, _lib.ptr(wn), _lib.ptr(bn), Cout, ks,
+              stride, act, groups, _lib.ptr(gn_), _lib.ptr(ben), _lib.ptr(rd), _lib.ptr(out), _lib.current_stream())
+    got = out.cpu()
+    err = (got - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, (B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res))
+
+
+@pytest.mark.parametrize("case", [
+    # B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res
+    (1, 1, 0, 24, 40, 24, 40, 64, 3, 1, 0, False),          # stem
+    (2, 64, 0, 32, 32, 32, 32, 64, 3, 1, 2, True),          # resblock conv2 + residual
+    (1, 128, 64, 16, 32, 16, 32, 64, 3, 1, 2, False),       # concat input, GN straddling the two sources (32 groups of 6)
+    (1, 8, 4, 33, 57, 33, 57, 8, 3, 1, 2, False),           # tiny channels, odd sizes (proj UNet level 0)
+    (1, 144, 0, 9, 7, 9, 7, 24, 3, 1, 2, False),            # 36 groups
+    (2, 64, 0, 31, 45, 31, 45, 64, 3, 2, 0, False),         # down-sample, odd input
+    (1, 16, 0, 29, 63, 57, 125, 16, 3, 1, 0, False),        # nearest up-sample to an explicit odd size
+    (1, 256, 0, 8, 8, 8, 8, 768, 1, 1, 1, False),           # qkv 1x1 with GN (no SiLU)
+    (2, 192, 0, 10, 12, 10, 12, 128, 1, 1, 0, True),        # shortcut 1x1 + residual
+    (1, 64, 0, 70, 100, 70, 100, 1, 3, 1, 2, False),        # out conv, Cout=1
+    (1, 130, 0, 12, 33, 12, 33, 70, 3, 1, 0, False),        # channels not multiples of the tile sizes
+])
+def test_conv_kernel(case):
+    _conv_case(*case, seed=200 + sum(case[:8]))
+
+
+@pytest.mark.parametrize("B,heads,T", [(1, 1, 35), (2, 4, 117), (1, 4, 1024), (1, 2, 1827), (1, 1, 7125)])
+def test_attention_kernel(B, heads, T):
+    from ipdm_pytorch_amd import _lib
+    d = 64
+    qkv = torch.from_numpy(synth.hash_normal((B, heads * 3 * d, T), 300 + T)) * 1.5
+    out = torch.empty((B, heads * d, T), device=DEV)
+    _lib.call("ipdm_op_attention", _lib.ptr(qkv.to(DEV)), _lib.ptr(out), B, heads, d, T, _lib.current_stream())
+    q, k, v = qkv.reshape(B * heads, 3 * d, T).chunk(3, dim=1)
+    scale = 1.0 / np.sqrt(np.sqrt(d))
+    attn = torch.einsum("bct,bcs->bts", (q * scale).double(), (k * scale).double()).softmax(dim=-1)
+    want = torch.einsum("bts,bcs->bct", attn, v.double()).reshape(B, heads * d, T).float()
+    assert (out.cpu() - want).abs().max() <= 2e-5
+
+
+def test_attention_softmax_rescale_branch():
+    """Online-softmax rescale: a late key block with a much larger score must take over (rule 26)."""
+    from ipdm_pytorch_amd import _lib
+    d, T = 64, 200
+    qkv = torch.from_numpy(synth.hash_normal((1, 3 * d, T), 77)) * 0.3
+    qkv[0, d:2 * d, 150] = qkv[0, 0:d, 10] * 40.0        # key 150 aligned with query 10 -> huge score late
+    out = torch.empty((1, d, T), device=DEV)
+    _lib.call("ipdm_op_attention", _lib.ptr(qkv.to(DEV)), _lib.ptr(out), 1, 1, d, T, _lib.current_stream())
+    q, k, v = qkv.reshape(1, 3 * d, T).double().chunk(3, dim=1)
+    attn = torch.einsum("bct,bcs->bts", q / 64 ** 0.25, k / 64 ** 0.25).softmax(dim=-1)
+    want = torch.einsum("bts,bcs->bct", attn, v).float()
+    assert (out.cpu() - want).abs().max() <= 2e-5
+    assert (out.cpu()[0, :, 10] - v[0, :, 150].float()).abs().max() < 1e-3
+
+
+# =========================================================================== UNet
+def _native_unet(kw, seed):
+    from ipdm_pytorch_amd.unet import UNetModel
+    net = UNetModel(**kw).to(DEV)
+    sd = synth.synth_state_dict(net._shapes, seed=seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net, {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_unet_small_golden(tag, golden):
+    g = golden("unet_small")
+    net, sd = _native_unet(SMALL_CFGS[tag], 11)
+    assert list(net._shapes.keys()) == list(g[tag + "_keys"])
+    x = torch.from_numpy(synth.hash_normal(SMALL_SHAPES[tag], 101))
+    for t in (0, 7):
+        got = net(x.to(DEV), torch.full((1,), t, dtype=torch.long)).cpu().numpy()
+        np.testing.assert_allclose(got, g["%s_t%d" % (tag, t)], rtol=0, atol=1e-5)
+
+
+def test_unet_head_dim_unsupported_fails_loudly():
+    from ipdm_pytorch_amd import IpdmError
+    net, _ = _native_unet(SMALL_CFGS["c"], 11)
+    with pytest.raises(IpdmError):
+        net(torch.zeros(SMALL_SHAPES["c"], device=DEV), 3)
+
+
+@pytest.mark.parametrize("which", ["img", "proj"])
+def test_unet_full_size_vs_oracle(which):
+    """The two production UNets at reduced spatial size (oracle time) incl. odd sizes for proj."""
+    if which == "img":
+        kw = dict(in_channels=1, model_channels=64, out_channels=1, attention_resolutions=(8, 16),
+                  channel_mult=(1, 1, 2, 2, 4, 4))
+        shape = (2, 1, 128, 128)
+    else:
+        kw = dict(in_channels=1, model_channels=64, out_channels=1, attention_resolutions=(16, 32),
+                  channel_mult=(1 / 16, 1 / 8, 1 / 4, 2, 2, 4, 4))
+        shape = (1, 1, 250, 114)       # -> 125x57 -> 63x29 -> 32x15 -> 16x8 ... odd sizes on the way
+    net, sd = _native_unet(kw, 5)
+    cfg = ou.UNetConfig(**kw)
+    x = torch.from_numpy(synth.hash_normal(shape, 400))
+    got = net(x.to(DEV), 11).cpu()
+    want = ou.unet_forward(cfg, sd, x, 11)
+    err = (got - want).abs().max().item()
+    assert err <= 5e-5 * max(1.0, want.abs().max().item()), err
+
+
+# =========================================================================== sampler loops
+def test_guided_reverse_process_golden(golden):
+    from ipdm_pytorch_amd.diffusion import GaussianDiffusion, InjectedNoise
+    g = golden("loops")
+    net, _ = _native_unet(LOOP_CFG, 41)
+    for tag, (mode, shape, power, kw) in LOOP_CASES.items():
+        gd = GaussianDiffusion(1000, "cosine", power)
+        img = (torch.from_numpy(synth.hash_uniform(shape, 42)) * 0.05 + 0.17) if mode == "img" else \
+            torch.from_numpy(synth.hash_uniform(shape, 43)) * 0.6
+        ldct = torch.from_numpy(synth.hash_uniform(shape, 44)) * 0.05 + 0.17
+        nd = int(g[tag + "_ndraws"])
+        draws = [torch.from_numpy(synth.hash_normal(shape, 45 * 1000 + k)) for k in range(nd)]
+        noise = InjectedNoise(draws)
+        res, _, _ = gd.guided_reverse_process(
+            model=net, img=img.to(DEV), mode=mode, lambda_curve=None, ldct=ldct.to(DEV), kernel_size_img=4,
+            amplitude_img=30, kernel_size_proj=4, amplitude_proj=7, only_convertor=False, normal=False,
+            noise_strength=None, noise=noise, **kw)
+        assert noise.draw == nd
+        got = np.stack([r.cpu().numpy() for r in res])
+        assert got.shape == g[tag].shape
+        np.testing.assert_allclose(got, g[tag], rtol=0, atol=5e-5)
+
+
+def test_guided_reverse_process_batch_equals_per_slice():
+    """Per-slice semantics + shard invariance: B=3 in one call == three B=1 calls (bit-identical)."""
+    from ipdm_pytorch_amd.diffusion import GaussianDiffusion, NoiseSource
+    net, _ = _native_unet(LOOP_CFG, 41)
+    gd = GaussianDiffusion(1000, "cosine", 5)
+    shape = (3, 1, 40, 24)
+    img = (torch.from_numpy(synth.hash_uniform(shape, 501)) * torch.tensor([0.6, 2.0, 0.1]).view(3, 1, 1, 1)).to(DEV)
+    kw = dict(model=net, t_start=[3, 2, 2], clip=False, lambda_ratio=1, eta=0.5, mode="proj", constant_guidance=None,
+              kernel_size_proj=4, amplitude_proj=7, only_convertor=False, normal=False)
+    full, _, _ = gd.guided_reverse_process(img=img, noise=NoiseSource(3, 0), **kw)
+    for b in range(3):
+        one, _, _ = gd.guided_reverse_process(img=img[b:b + 1], noise=NoiseSource(3, b), **kw)
+        for k in range(len(full)):
+            assert torch.equal(full[k][b:b + 1], one[k]), (b, k)
+
+
+# =========================================================================== end to end
+def test_smoke_pipeline_matches_oracle_psnr():
+    """proj GRP -> FBP -> sharpen -> img GRP -> ultra on a real-geometry phantom sinogram, reduced UNets.
+    north_star: PSNR (vs ground truth, on miu2pixel images) within 1e-4 relative of the CPU path."""
+    from ipdm_pytorch_amd.denoiser import smoke_pipeline
+    from oracle import pipeline as op
+    got, inputs = smoke_pipeline(DEV)
+    want = op.smoke_pipeline_oracle(inputs)
+    assert got.shape == want.shape == (1, 1, 512, 512)
+    assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max())
+    truth = od.miu2pixel(torch.from_numpy(synth.rasterize(synth.ellipse_phantom(1)))).numpy()
+    p_hip = od.psnr(truth, od.miu2pixel(torch.from_numpy(got[0, 0])).numpy())
+    p_cpu = od.psnr(truth, od.miu2pixel(torch.from_numpy(want[0, 0])).numpy())
+    assert abs(p_hip - p_cpu) <= 1e-4 * abs(p_cpu), (p_hip, p_cpu)
+
+
+def test_drop_in_surface():
+    """update_opt / reset_opt / result dicts behave as the reference's (Utils/train_test_utils.py:202-211,45-56)."""
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, ResultTempDict
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    den = progressive_domain_denoiser(opt)
+    den.update_opt(dict(convertor="FBP", save_it_state_img=False, ultra_img_denoise=False, not_a_key=1))
+    assert den.opt.ultra_img_denoise is False and not hasattr(den.opt, "not_a_key")
+    den.reset_opt()
+    assert den.opt.ultra_img_denoise is True
+    with pytest.raises(AttributeError):
+        den.update_opt(None)
+    d = ResultTempDict()
+    d["iter_1"], d["iter_2"] = 1, 2
+    assert d[1] == 1 and d[-1] == 2 and d["iter_2"] == 2
+    den.update_opt(dict(benchmark_test=True))
+    x = torch.zeros((1, 1, 2000, 912))
+    den.data_sample_load(ldproj=x)
+    out, ns = den.proj_denoiser(den.ldproj, save_state=False)      # only_convertor short-circuit: FBP of the input
+    assert isinstance(out, torch.Tensor) and out.device.type == "cpu" and tuple(out.shape) == (1, 1, 512, 512) and ns is None
