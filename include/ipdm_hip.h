@@ -164,6 +164,14 @@ int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, int32_t C2,
 int ipdm_op_attention(const float *d_qkv, float *d_out, int32_t B, int32_t heads, int32_t d, int32_t T,
                       void *stream);
 
+/* ------------------------------------------------------------------ measurement ------------- */
+/* Per-launch HIP-event timing of the hot kernels on their launch stream (bench.py roofline leg; no
+ * reference counterpart -- the reference has no profiling).  Classes: 0 = conv 3x3
+ * stride-1 wide tile (dominant kernel), 1 = other conv variants, 2 = attention.  ipdm_profile_end needs
+ * the stream synchronised; outputs are arrays of 3. */
+int ipdm_profile_begin(int32_t max_launches);
+int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,8 +146,11 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
     // scale = 1/sqrt(sqrt(C/heads)) (Model/model.py:149); python double -> f32 scalar
     const float scale = (float)(1.0 / sqrt(sqrt((double)d)));
     dim3 grid(cdiv(T, 128), B * heads);
+    const bool prof = prof_enabled();
+    if (prof) prof_before(2, st);
     if (d == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, st, qkv, out, heads, T, scale);
     else hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, st, qkv, out, heads, T, scale);
+    if (prof) prof_after(2, 4.0 * B * heads * (double)T * T * d, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }

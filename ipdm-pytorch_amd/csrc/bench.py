@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py -- CT slices/s of the full dual-domain partial-diffusion sample on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic 0.25-dose slices per GPU:
+proj-domain guided reverse process (t_start_proj=[15,15,15], adaptive guidance, 45 UNet forwards at
+2000x912) -> HIP FBP to 512x512 -> sharpen -> img-domain guided reverse process (t_start_img=[15],
+15 forwards) -> "ultra" pass ([5,5,5], 15 forwards), then ONE all-gather of the outputs over ranks.
+Inputs are resident in HBM when the timed region starts; weights are random-init of the reference
+architectures (no checkpoints exist offline).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak (= f32 vector peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="slices per GPU (weak scaling: fixed per GPU)")
+    ap.add_argument("--t_start_proj", type=int, nargs="+", default=[15, 15, 15])
+    ap.add_argument("--t_start_img", type=int, nargs="+", default=[15])
+    ap.add_argument("--no-ultra", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_inputs(batch, slice_id0, device):
+    """Synthetic 0.25-dose sinograms of ellipse phantoms, keyed by global slice id."""
+    import numpy as np
+    import torch
+    from ipdm_pytorch_amd import synth
+    sinos = []
+    for b in range(batch):
+        sid = slice_id0 + b
+        sinos.append(synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(sid % 16)), seed=sid))
+    return torch.from_numpy(np.stack(sinos))[:, None].to(device)
+
+
+def cpu_baseline():
+    """The CPU oracle (a port: torch-CPU UNet restatement + C FBP) timed on this host's cores on a bounded
+    sample -- 1 proj-UNet forward @2000x912, 1 img-UNet forward @512x512, 1 FBP -- extrapolated by the exact
+    call counts of one slice (45 proj + 30 img forwards + 1 FBP)."""
+    import numpy as np
+    import torch
+    from oracle import unet as ou, fbp as of
+    from ipdm_pytorch_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    out = {}
+    for name, cfg, shape in (("img", ou.UNetConfig(), (1, 1, 512, 512)),
+                             ("proj", ou.UNetConfig(attention_resolutions=(16, 32),
+                                                    channel_mult=(1 / 16, 1 / 8, 1 / 4, 2, 2, 4, 4)), (1, 1, 2000, 912))):
+        sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg), seed=1).items()}
+        x = torch.from_numpy(synth.hash_normal(shape, 3))
+        t0 = time.perf_counter()
+        ou.unet_forward(cfg, sd, x, 7)
+        out[name] = time.perf_counter() - t0
+    geo = of.FBPGeometry()
+    sino = synth.hash_uniform((1, 2000, 912), 5) * 4
+    t0 = time.perf_counter()
+    of.convert(geo, sino)
+    out["fbp"] = time.perf_counter() - t0
+    return out, cores
+
+
+def main():
+    args = parse()
+    import torch
+    import ipdm_pytorch_amd
+    from ipdm_pytorch_amd import _lib, dist as idist
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser
+
+    rank, world, local = idist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    device = "cuda:%d" % local
+    torch.cuda.set_device(local)
+
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    cfg_load(dict(device=device, t_start_proj=args.t_start_proj, t_start_img=args.t_start_img,
+                  ultra_img_denoise=not args.no_ultra), opt.__dict__)
+    B = args.batch
+    n_global = B * world
+    lo, hi = idist.shard_range(n_global, rank, world)
+    den = progressive_domain_denoiser(opt, seed=1234, slice_id0=lo)
+    ldproj = make_inputs(B, lo, device)
+    den.data_sample_load(ldproj=ldproj)
+    n_fwd_proj = sum(args.t_start_proj)
+    n_fwd_img = sum(args.t_start_img) + (0 if args.no_ultra else 15)
+
+    def step():
+        out = den.progressive_denoiser_device(sharpen_num=70)
+        return idist.all_gather_slices(out, n_global, rank, world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    idist.barrier()
+    prof = (not args.no_roofline) and rank == 0
+    if prof:
+        _lib.call("ipdm_profile_begin", 200000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    idist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = idist.max_over_ranks(elapsed, device)
+    roofline = None
+    extra = {}
+    if prof:
+        fl, ms, nl = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int64 * 3)()
+        _lib.call("ipdm_profile_end", C.byref(fl), C.byref(ms), C.byref(nl))
+        if nl[0]:
+            ach = fl[0] / (ms[0] * 1e-3) / 1e12
+            roofline = {"kernel": "conv_igemm_kernel<3,1,2,2> (3x3 s1 implicit GEMM, f32 MFMA)", "bound": "mfma",
+                        "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches": int(nl[0]), "avg_launch_ms": round(ms[0] / nl[0], 4),
+                        "avg_launch_gflop": round(fl[0] / nl[0] / 1e9, 3)}
+        for c, name in ((1, "conv_other"), (2, "attention")):
+            if nl[c]:
+                extra[name] = {"tflops": round(fl[c] / (ms[c] * 1e-3) / 1e12, 2), "ms_total": round(ms[c], 2),
+                               "launches": int(nl[c])}
+        extra["dominant_kernel_time_share"] = round(ms[0] * 1e-3 / elapsed, 4) if nl[0] else None
+    if rank == 0:
+        assert out.shape[0] == n_global and bool(torch.isfinite(out).all())
+        value = n_global * args.steps / elapsed
+        line = {
+            "metric": "CT slices/s (full proj+img partial-diffusion sample)", "value": round(value, 5),
+            "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full dual-domain progressive sample: proj UNet x%d @2000x912 + HIP FBP + img UNet x%d "
+                                   "@512x512, t_start_proj=%s t_start_img=%s ultra=%s" % (
+                                       n_fwd_proj, n_fwd_img, args.t_start_proj, args.t_start_img, not args.no_ultra),
+                       "slices_per_gpu": B, "global_batch": n_global, "parallelism": "slice-sharded x%d" % world,
+                       "weights": "random-init reference architectures (29.1M img / 28.4M proj params)"},
+            "roofline": roofline, "kernels": extra,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            tb, cores = cpu_baseline()
+            per_slice = n_fwd_proj * tb["proj"] + n_fwd_img * tb["img"] + tb["fbp"]
+            line["cpu_baseline"] = {
+                "value": round(1.0 / per_slice, 6), "unit": "slices/s", "cores": cores, "kind": "port",
+                "sample": "oracle timed on 1 proj-UNet fwd @2000x912 (%.1fs), 1 img-UNet fwd @512x512 (%.1fs), 1 FBP "
+                          "(%.1fs); extrapolated by call counts %d/%d/1 per slice" % (
+                              tb["proj"], tb["img"], tb["fbp"], n_fwd_proj, n_fwd_img)}
+            line["speedup_vs_cpu_baseline"] = round(value * per_slice, 1)
+        print(json.dumps(line))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

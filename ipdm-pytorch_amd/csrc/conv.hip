@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a)
 template <int KS, int STRIDE, int MB, int NB>
 static int launch_conv(const ConvArgs &args, hipStream_t st)
 {
+    constexpr int prof_cls = (KS == 3 && STRIDE == 1 && MB == 2) ? 0 : 1;
     using T = ConvTile<KS, STRIDE, MB, NB>;
     ConvArgs a = args;
     a.tiles_x = cdiv(a.Wo, T::TW);
@@ -220,7 +221,10 @@ static int launch_conv(const ConvArgs &args, hipStream_t st)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
         attr_set = true;
     }
+    const bool prof = prof_enabled();
+    if (prof) prof_before(prof_cls, st);
     hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, MB, NB>), dim3((unsigned)nwg), dim3(256), T::LDS_BYTES, st, a);
+    if (prof) prof_after(prof_cls, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }

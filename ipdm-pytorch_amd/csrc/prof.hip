@@ -1,0 +1,68 @@
+// Per-launch HIP-event timing of the hot kernels, on the stream they are launched on (bench.py's
+// roofline leg: achieved = algorithmic FLOPs of a launch / its measured duration).  Off by default:
+// zero cost on the product path.
+#include <vector>
+#include "unet_kernels.h"
+
+namespace ipdm {
+namespace {
+struct Rec { hipEvent_t a, b; int cls; double flops; };
+struct Prof {
+    bool on = false;
+    std::vector<Rec> pool;
+    size_t used = 0;
+    hipEvent_t pending = nullptr;
+} g_prof;
+}  // namespace
+
+bool prof_enabled() { return g_prof.on && g_prof.used < g_prof.pool.size(); }
+void prof_before(int cls, hipStream_t st)
+{
+    Rec &r = g_prof.pool[g_prof.used];
+    r.cls = cls;
+    (void)hipEventRecord(r.a, st);
+}
+void prof_after(int cls, double flops, hipStream_t st)
+{
+    Rec &r = g_prof.pool[g_prof.used++];
+    r.flops = flops;
+    (void)hipEventRecord(r.b, st);
+}
+}  // namespace ipdm
+
+using namespace ipdm;
+
+// Starts recording up to max_launches kernel launches (events are created once and reused).
+extern "C" int ipdm_profile_begin(int32_t max_launches)
+{
+    IPDM_REQUIRE(max_launches > 0, "profile_begin: bad capacity");
+    while ((int)g_prof.pool.size() < max_launches) {
+        Rec r;
+        IPDM_HIP_CHECK(hipEventCreate(&r.a));
+        IPDM_HIP_CHECK(hipEventCreate(&r.b));
+        r.cls = 0; r.flops = 0;
+        g_prof.pool.push_back(r);
+    }
+    g_prof.used = 0;
+    g_prof.on = true;
+    return IPDM_OK;
+}
+
+// Stops recording; the caller must have synchronised the stream.  out_* are arrays of PROF_CLASSES
+// entries: total algorithmic FLOPs, total kernel milliseconds, launch count per class.
+extern "C" int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches)
+{
+    IPDM_REQUIRE(out_flops && out_ms && out_launches, "profile_end: null argument");
+    g_prof.on = false;
+    for (int c = 0; c < PROF_CLASSES; ++c) { out_flops[c] = 0; out_ms[c] = 0; out_launches[c] = 0; }
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        const Rec &r = g_prof.pool[i];
+        float ms = 0.f;
+        IPDM_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+        out_flops[r.cls] += r.flops;
+        out_ms[r.cls] += ms;
+        out_launches[r.cls] += 1;
+    }
+    g_prof.used = 0;
+    return IPDM_OK;
+}

@@ -25,6 +25,13 @@ struct ConvArgs {
 };
 
 int conv2d_launch(const ConvArgs &a, hipStream_t st);
+
+// per-launch HIP-event timing of kernel classes (bench.py roofline): 0 = conv 3x3 s1 wide tile (the
+// dominant kernel), 1 = every other conv variant, 2 = attention
+constexpr int PROF_CLASSES = 3;
+bool prof_enabled();
+void prof_before(int cls, hipStream_t st);
+void prof_after(int cls, double flops, hipStream_t st);
 void conv_pack_weights(const float *w, int Cout, int Cin, int ks, std::vector<float> &packed, int &cin_pad, int &cout_pad);
 
 // GroupNorm statistics over (possibly concatenated) NCHW sources -> per-(sample,channel) affine
