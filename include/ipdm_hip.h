@@ -172,6 +172,11 @@ int ipdm_op_attention(const float *d_qkv, float *d_out, int32_t B, int32_t heads
 int ipdm_profile_begin(int32_t max_launches);
 int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches);
 
+/* kernel micro-benchmarks (tuning aid; allocate, fill with random data, time `iters` launches) */
+int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, int32_t W, int32_t Cout, int32_t ksize,
+                      int32_t stride, int32_t act, int32_t with_res, int32_t iters, float *avg_ms);
+int ipdm_bench_attention(int32_t B, int32_t heads, int32_t d, int32_t T, int32_t iters, float *avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,19 +18,25 @@
 // Tiling: workgroup = 4 waves; tile = (4*NB rows) x 32 cols of output pixels x (32*MB) couts; wave w
 //   owns rows [w*NB, (w+1)*NB) -> MB x NB accumulator tiles of 32x32.  K is walked in chunks of KC
 //   input channels: the (halo'ed) input tile [KC][IN_ROWS][IN_COLS] and the weight slab
-//   [KC][taps][32*MB] are double-buffered in LDS; chunk c+1 is prefetched into registers while
-//   chunk c feeds the MFMAs.  All LDS operand reads are 32 consecutive dwords per half-wave
-//   (conflict-free for ds_read_b32).
+//   [KC][taps][32*MB] are double-buffered in LDS.
+// Pipeline per chunk: (1) issue the RAW global loads of chunk c+1 (branch-free: scalar channel base +
+//   per-thread clamped spatial offset, all in flight together), (2) run the MFMAs of chunk c out of
+//   LDS, (3) only then apply GroupNorm/SiLU (scale/shift are wave-uniform per channel -> scalar
+//   operands) and write chunk c+1 to the other LDS buffer, (4) one barrier.  The global-load latency
+//   is therefore hidden behind ~9k cycles of MFMA work.  All LDS operand reads are 32 consecutive
+//   dwords per half-wave (conflict-free ds_read_b32).
+#include <type_traits>
 #include "common.h"
 #include "unet_kernels.h"
 
 using namespace ipdm;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int STRIDE, int MB, int NB>
+template <int KS, int STRIDE, int MB, int NB, int KC_>
 struct ConvTile {
-    static constexpr int KC = 8;
+    static constexpr int KC = KC_;
     static constexpr int TAPS = KS * KS;
     static constexpr int TH = 4 * NB;                       // output rows per workgroup
     static constexpr int TW = 32;                           // output cols per workgroup
@@ -40,17 +46,22 @@ struct ConvTile {
     static constexpr int IN_TILE = KC * IN_CH;
     static constexpr int BN = 32 * MB;                      // couts per workgroup
     static constexpr int W_TILE = KC * TAPS * BN;
-    static constexpr int IN_PER_THREAD = (IN_TILE + 255) / 256;
-    static constexpr int W_VEC_PER_THREAD = (W_TILE / 4 + 255) / 256;
+    static constexpr int SP = (IN_CH + 255) / 256;          // spatial positions per thread per channel
+    static constexpr int W_VEC = (W_TILE / 4 + 255) / 256;  // float4 weight loads per thread per chunk
     static constexpr size_t LDS_BYTES = (size_t)2 * (IN_TILE + W_TILE) * sizeof(float);
 };
 
-__device__ inline float silu_f(float v) { return v / (1.0f + expf(-v)); }
+// SiLU with the hardware exp2/rcp (each ~1 ulp): |err| ~ 3e-7 relative, far inside the parity budget
+__device__ inline float silu_fast(float v)
+{
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * v);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
-template <int KS, int STRIDE, int MB, int NB>
+template <int KS, int STRIDE, int MB, int NB, int KC>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a)
 {
-    using T = ConvTile<KS, STRIDE, MB, NB>;
+    using T = ConvTile<KS, STRIDE, MB, NB, KC>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BUF = T::IN_TILE + T::W_TILE;   // floats per stage: [input tile | weight slab]
 
@@ -62,9 +73,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a)
         const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int co_tiles = a.co_tiles;
-    const int co_t = wid % co_tiles;
-    int rest = wid / co_tiles;
+    const int co_t = wid % a.co_tiles;
+    int rest = wid / a.co_tiles;
     const int tx = rest % a.tiles_x; rest /= a.tiles_x;
     const int ty = rest % a.tiles_y;
     const int n = rest / a.tiles_y;
@@ -72,71 +82,78 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a)
     const int iy0 = oy0 * STRIDE - KS / 2, ix0 = ox0 * STRIDE - KS / 2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lk = lane >> 5, l31 = lane & 31;
     const int Ctot = a.C1 + a.C2;
-    const size_t src_plane = (size_t)a.Hs * a.Ws;
+    const int src_plane = a.Hs * a.Ws;
 
-    // ---- per-thread staging descriptors (independent of the channel chunk)
-    int in_off[T::IN_PER_THREAD];      // source offset inside a channel plane, or -1 (zero padding)
+    // ---- per-thread spatial descriptors (the same for every channel): clamped source offset + validity
+    int sp_off[T::SP];
+    bool sp_ok[T::SP];
 #pragma unroll
-    for (int e = 0; e < T::IN_PER_THREAD; ++e) {
-        const int idx = tid + e * 256;
-        const int sp = idx % T::IN_CH;
+    for (int j = 0; j < T::SP; ++j) {
+        const int sp = tid + j * 256;
         const int r = sp / T::IN_COLS, c = sp % T::IN_COLS;
         const int iy = iy0 + r, ix = ix0 + c;
-        int off = -1;
-        if (idx < T::IN_TILE && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-            int sy = iy, sx = ix;
-            if (a.upsample) {   // F.interpolate(mode="nearest"): src = min(floor(dst * (in/out) in f32), in-1)
-                sy = min((int)floorf((float)iy * a.scale_y), a.Hs - 1);
-                sx = min((int)floorf((float)ix * a.scale_x), a.Ws - 1);
-            }
-            off = sy * a.Ws + sx;
+        const bool ok = sp < T::IN_CH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        int sy = min(max(iy, 0), a.H - 1), sx = min(max(ix, 0), a.W - 1);
+        if (a.upsample) {   // F.interpolate(mode="nearest"): src = min(floor(dst * (in/out) in f32), in-1)
+            sy = min((int)floorf((float)sy * a.scale_y), a.Hs - 1);
+            sx = min((int)floorf((float)sx * a.scale_x), a.Ws - 1);
         }
-        in_off[e] = off;
+        sp_off[j] = sy * a.Ws + sx;
+        sp_ok[j] = ok;
     }
 
-    float in_reg[T::IN_PER_THREAD];
-    float4 w_reg[T::W_VEC_PER_THREAD];
+    float raw[KC][T::SP];
+    f32x4 w_reg[T::W_VEC];
 
-    auto load_chunk = [&](int c0) {
+    // (1) raw loads of one chunk: channel base is wave-uniform (scalar), offsets are per-thread constants
+    auto load_chunk = [&](int c0) __attribute__((always_inline)) {
+        // the launcher guarantees a chunk never straddles the two sources (C1 % KC == 0 when C2 > 0)
+        const bool from1 = c0 < a.C1;
+        const float *base = from1 ? a.x1 + ((size_t)n * a.C1 + c0) * src_plane
+                                  : a.x2 + ((size_t)n * a.C2 + (c0 - a.C1)) * src_plane;
+        const int cend = (from1 ? a.C1 : Ctot) - c0;           // channels of this source left from c0
 #pragma unroll
-        for (int e = 0; e < T::IN_PER_THREAD; ++e) {
-            const int idx = tid + e * 256;
-            const int c = c0 + idx / T::IN_CH;
-            float v = 0.0f;
-            if (in_off[e] >= 0 && c < Ctot) {
-                const float *src = (c < a.C1) ? a.x1 + ((size_t)n * a.C1 + c) * src_plane
-                                              : a.x2 + ((size_t)n * a.C2 + (c - a.C1)) * src_plane;
-                v = src[in_off[e]];
-                if (a.act) {
-                    v = v * a.gn_scale[(size_t)n * Ctot + c] + a.gn_shift[(size_t)n * Ctot + c];
-                    if (a.act == 2) v = silu_f(v);
-                }
-            }
-            in_reg[e] = v;
+        for (int c = 0; c < KC; ++c) {
+            const float *pc = base + (size_t)min(c, cend - 1) * src_plane;   // clamp: never reads past the tensor
+#pragma unroll
+            for (int j = 0; j < T::SP; ++j) raw[c][j] = pc[sp_off[j]];
         }
-        // weights packed [Cin_pad][TAPS][Cout_pad] (Cout_pad multiple of 64, Cin_pad of KC): one KC chunk
-        // of a BN-wide cout slab = KC*TAPS rows of BN floats
 #pragma unroll
-        for (int e = 0; e < T::W_VEC_PER_THREAD; ++e) {
-            const int v4 = tid + e * 256;
-            if (v4 < T::W_TILE / 4) {
-                const int row = v4 / (T::BN / 4), col4 = v4 % (T::BN / 4);
-                w_reg[e] = *reinterpret_cast<const float4 *>(a.w + ((size_t)c0 * T::TAPS + row) * a.cout_pad + co0 + col4 * 4);
-            }
+        for (int e = 0; e < T::W_VEC; ++e) {
+            const int v4 = min(tid + e * 256, T::W_TILE / 4 - 1);      // clamped: unconditional load keeps w_reg in VGPRs
+            const int row = v4 / (T::BN / 4), col4 = v4 % (T::BN / 4);
+            w_reg[e] = *reinterpret_cast<const f32x4 *>(a.w + ((size_t)c0 * T::TAPS + row) * a.cout_pad + co0 + col4 * 4);
         }
     };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < T::IN_PER_THREAD; ++e) {
-            const int idx = tid + e * 256;
-            if (idx < T::IN_TILE) lds[buf * BUF + idx] = in_reg[e];
-        }
-#pragma unroll
-        for (int e = 0; e < T::W_VEC_PER_THREAD; ++e) {
+    // (3) GroupNorm/SiLU + zero padding, then LDS.  Split into KC*SP + W_VEC independent items so that the
+    //     main loop can interleave them with the MFMAs of the current chunk (no VALU-only bubble per chunk).
+    constexpr int N_IN_ITEMS = KC * T::SP;
+    constexpr int N_ITEMS = N_IN_ITEMS + T::W_VEC;
+    auto store_item = [&](int buf, int c0, int item) __attribute__((always_inline)) {
+        float *ib = lds + buf * BUF;
+        if (item < N_IN_ITEMS) {
+            const int c = item / T::SP, j = item % T::SP;
+            const int nvalid = Ctot - c0;                      // channels >= nvalid are zero padding
+            const int sp = tid + j * 256;
+            float v = raw[c][j];
+            if (a.act) {                                        // wave-uniform channel -> scalar loads of scale/shift
+                const int cc = min(c, nvalid - 1);
+                v = v * a.gn_scale[(size_t)n * Ctot + c0 + cc] + a.gn_shift[(size_t)n * Ctot + c0 + cc];
+                if (a.act == 2) v = silu_fast(v);
+            }
+            v = (sp_ok[j] && c < nvalid) ? v : 0.0f;
+            if (T::IN_CH % 256 == 0 || sp < T::IN_CH) ib[c * T::IN_CH + sp] = v;
+        } else {
+            const int e = item - N_IN_ITEMS;
             const int v4 = tid + e * 256;
-            if (v4 < T::W_TILE / 4) *reinterpret_cast<float4 *>(lds + buf * BUF + T::IN_TILE + v4 * 4) = w_reg[e];
+            if (v4 < T::W_TILE / 4) *reinterpret_cast<f32x4 *>(ib + T::IN_TILE + v4 * 4) = w_reg[e];
         }
+    };
+    auto store_chunk = [&](int buf, int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int item = 0; item < N_ITEMS; ++item) store_item(buf, c0, item);
     };
 
     f32x16 acc[MB][NB];
@@ -147,83 +164,174 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.0f;
 
-    const int nchunks = (Ctot + T::KC - 1) / T::KC;
+    const int nchunks = (Ctot + KC - 1) / KC;
     load_chunk(0);
-    store_chunk(0);
+    store_chunk(0, 0);
     __syncthreads();
 
-    const int lk = lane >> 5, l31 = lane & 31;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
-        if (ch + 1 < nchunks) load_chunk((ch + 1) * T::KC);
+        const bool more = ch + 1 < nchunks;
+        if (more) load_chunk((ch + 1) * KC);
         const float *ib = lds + cur * BUF;
         const float *wb = ib + T::IN_TILE;
-        const int kc_eff = min(T::KC, Ctot - ch * T::KC);
+        const int kc_eff = min(KC, Ctot - ch * KC);
         const int npairs = (kc_eff + 1) >> 1;
-        for (int cp = 0; cp < npairs; ++cp) {
+        // Operand registers: B = the ROWS x KS input values of one channel pair this wave touches (loaded one
+        // pair ahead), A = the MB weight values of one tap (loaded one tap ahead).  LDS latency is hidden behind
+        // the 4 MFMAs (256 cycles) of the current tap; sched_barrier pins that order.
+        constexpr int ROWS = (NB - 1) * STRIDE + KS;
+        constexpr int NP = KC / 2;
+        auto read_b = [&](int cp, float (&Bv)[ROWS][KS]) __attribute__((always_inline)) {
             const int c = cp * 2 + lk;
 #pragma unroll
-            for (int ky = 0; ky < KS; ++ky)
+            for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    float av[MB], bv[NB];
+                for (int kx = 0; kx < KS; ++kx)
+                    Bv[r][kx] = ib[c * T::IN_CH + (wave * NB * STRIDE + r) * T::IN_COLS + l31 * STRIDE + kx];
+        };
+        auto read_a = [&](int cp, int t, float (&A)[MB]) __attribute__((always_inline)) {
+            const int c = cp * 2 + lk;
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) av[m] = wb[(c * T::TAPS + ky * KS + kx) * T::BN + m * 32 + l31];
+            for (int m = 0; m < MB; ++m) A[m] = wb[(c * T::TAPS + t) * T::BN + m * 32 + l31];
+        };
+        // one full chunk (KC channels), compile-time schedule; with_store: the staging items of chunk ch+1 are
+        // spread between the MFMA groups from the second channel pair on (their loads were issued >2k cycles ago)
+        auto full_chunk = [&](auto with_store) __attribute__((always_inline)) {
+            constexpr bool WS = decltype(with_store)::value;
+            constexpr int SLOTS = (NP > 1 ? NP - 1 : 1) * T::TAPS;
+            constexpr int PER_SLOT = (N_ITEMS + SLOTS - 1) / SLOTS;
+            float b_cur[ROWS][KS], b_nxt[ROWS][KS], a_c[MB], a_n[MB];
+            read_b(0, b_cur);
+            read_a(0, 0, a_c);
 #pragma unroll
-                    for (int q = 0; q < NB; ++q)
-                        bv[q] = ib[c * T::IN_CH + ((wave * NB + q) * STRIDE + ky) * T::IN_COLS + l31 * STRIDE + kx];
+            for (int cp = 0; cp < NP; ++cp) {
+                if (cp + 1 < NP) read_b(cp + 1, b_nxt);
+#pragma unroll
+                for (int t = 0; t < T::TAPS; ++t) {
+                    if (t + 1 < T::TAPS) read_a(cp, t + 1, a_n);
+                    else if (cp + 1 < NP) read_a(cp + 1, 0, a_n);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
                         for (int q = 0; q < NB; ++q)
-                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[q], acc[m][q], 0, 0, 0);
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[m], b_cur[q * STRIDE + t / KS][t % KS], acc[m][q], 0, 0, 0);
+                    if (WS) {
+                        const int slot = (NP > 1 ? cp - 1 : cp) * T::TAPS + t;
+                        if (slot >= 0) {
+#pragma unroll
+                            for (int k = 0; k < PER_SLOT; ++k)
+                                if (slot * PER_SLOT + k < N_ITEMS) store_item(cur ^ 1, (ch + 1) * KC, slot * PER_SLOT + k);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) a_c[m] = a_n[m];
                 }
+                if (cp + 1 < NP) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                        for (int kx = 0; kx < KS; ++kx) b_cur[r][kx] = b_nxt[r][kx];
+                }
+            }
+        };
+        bool stored = false;
+        if (kc_eff == KC) {
+            if (more) { full_chunk(std::true_type{}); stored = true; }
+            else full_chunk(std::false_type{});
+        } else {
+            // partial chunk (Cin not a multiple of KC): plain schedule
+            for (int cp = 0; cp < npairs; ++cp) {
+                float b_cur[ROWS][KS], a_c[MB];
+                read_b(cp, b_cur);
+#pragma unroll
+                for (int t = 0; t < T::TAPS; ++t) {
+                    read_a(cp, t, a_c);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int q = 0; q < NB; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[m], b_cur[q * STRIDE + t / KS][t % KS], acc[m][q], 0, 0, 0);
+                }
+            }
         }
-        if (ch + 1 < nchunks) store_chunk(cur ^ 1);
+        if (more && !stored) store_chunk(cur ^ 1, (ch + 1) * KC);
         __syncthreads();
     }
 
     // ---- epilogue: + bias (+ residual), coalesced NCHW stores (32 consecutive pixels per half-wave)
     const int ox = ox0 + l31;
     const size_t out_plane = (size_t)a.Ho * a.Wo;
+    const bool full = (oy0 + T::TH <= a.Ho) && (ox0 + T::TW <= a.Wo) && (co0 + T::BN <= a.Cout);   // workgroup-uniform
+    if (full) {
+        // fast path: no bounds checks, all residual loads of a 32x32 tile in flight together
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < MB; ++m) {
+            float bv[16];
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int oy = oy0 + wave * NB + q;
+            for (int r = 0; r < 16; ++r) bv[r] = a.bias ? a.bias[co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (co < a.Cout && oy < a.Ho && ox < a.Wo) {
-                    const size_t o = ((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wo + ox;
-                    float v = acc[m][q][r];
-                    if (a.bias) v += a.bias[co];
-                    if (a.res) v += a.res[o];
-                    a.out[o] = v;
+            for (int q = 0; q < NB; ++q) {
+                const int oy = oy0 + wave * NB + q;
+                const size_t o0 = ((size_t)n * a.Cout + co0 + m * 32 + 4 * lk) * out_plane + (size_t)oy * a.Wo + ox;
+                float rv[16];
+                if (a.res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = a.res[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * out_plane];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[m][q][r] + bv[r];
+                    if (a.res) v += rv[r];
+                    a.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * out_plane] = v;
                 }
             }
         }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int oy = oy0 + wave * NB + q;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (co < a.Cout && oy < a.Ho && ox < a.Wo) {
+                        const size_t o = ((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wo + ox;
+                        float v = acc[m][q][r];
+                        if (a.bias) v += a.bias[co];
+                        if (a.res) v += a.res[o];
+                        a.out[o] = v;
+                    }
+                }
+            }
+    }
 }
 
-template <int KS, int STRIDE, int MB, int NB>
+template <int KS, int STRIDE, int MB, int NB, int KC>
 static int launch_conv(const ConvArgs &args, hipStream_t st)
 {
+    using T = ConvTile<KS, STRIDE, MB, NB, KC>;
     constexpr int prof_cls = (KS == 3 && STRIDE == 1 && MB == 2) ? 0 : 1;
-    using T = ConvTile<KS, STRIDE, MB, NB>;
     ConvArgs a = args;
     a.tiles_x = cdiv(a.Wo, T::TW);
     a.tiles_y = cdiv(a.Ho, T::TH);
     a.co_tiles = cdiv(a.Cout, T::BN);
+    IPDM_REQUIRE(a.C2 == 0 || a.C1 % KC == 0, "conv2d: concat split %d not a multiple of the K chunk %d", a.C1, KC);
+    IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 31) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 31),
+                 "conv2d: per-sample tensor exceeds 32-bit offsets");
     const long nwg = (long)a.tiles_x * a.tiles_y * a.co_tiles * a.B;
     static bool attr_set = false;
     if (!attr_set) {
-        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_igemm_kernel<KS, STRIDE, MB, NB>,
+        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_igemm_kernel<KS, STRIDE, MB, NB, KC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
         attr_set = true;
     }
     const bool prof = prof_enabled();
     if (prof) prof_before(prof_cls, st);
-    hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, MB, NB>), dim3((unsigned)nwg), dim3(256), T::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, MB, NB, KC>), dim3((unsigned)nwg), dim3(256), T::LDS_BYTES, st, a);
     if (prof) prof_after(prof_cls, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
@@ -237,12 +345,14 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
     IPDM_REQUIRE(a.C2 == 0 || a.x2, "conv2d: second source missing");
     IPDM_REQUIRE(!a.act || (a.gn_scale && a.gn_shift), "conv2d: GN prologue without scale/shift");
     const bool wide = a.Cout > 32;
-    if (a.ksize == 3 && a.stride == 1) return wide ? launch_conv<3, 1, 2, 2>(a, st) : launch_conv<3, 1, 1, 2>(a, st);
-    if (a.ksize == 3 && a.stride == 2) return wide ? launch_conv<3, 2, 2, 1>(a, st) : launch_conv<3, 2, 1, 1>(a, st);
-    if (a.ksize == 1 && a.stride == 1) return wide ? launch_conv<1, 1, 2, 2>(a, st) : launch_conv<1, 1, 1, 2>(a, st);
+    if (a.ksize == 3 && a.stride == 1) return wide ? launch_conv<3, 1, 2, 2, 8>(a, st) : launch_conv<3, 1, 1, 2, 8>(a, st);
+    if (a.ksize == 3 && a.stride == 2) return wide ? launch_conv<3, 2, 2, 1, 8>(a, st) : launch_conv<3, 2, 1, 1, 8>(a, st);
+    if (a.ksize == 1 && a.stride == 1) return wide ? launch_conv<1, 1, 2, 2, 8>(a, st) : launch_conv<1, 1, 1, 2, 8>(a, st);
     set_error("conv2d: unsupported ksize=%d stride=%d", a.ksize, a.stride);
     return IPDM_ERR_UNSUPPORTED;
 }
+
+int conv_k_chunk() { return 8; }
 
 // Repack reference-layout weights [Cout][Cin][k][k] (host) -> [Cin_pad][k*k][Cout_pad] (host), zero padded.
 void conv_pack_weights(const float *w, int Cout, int Cin, int ks, std::vector<float> &packed, int &cin_pad, int &cout_pad)

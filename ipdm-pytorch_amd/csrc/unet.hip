@@ -624,6 +624,18 @@ struct Fwd {
     Tensor *run_block(const std::vector<Layer> &layers, Tensor *x1, Tensor *x2, int size_h, int size_w)
     {
         Tensor *h = nullptr;
+        Tensor *cat = nullptr;
+        if (x2 && (x1->C % conv_k_chunk()) != 0) {
+            // the conv kernel walks K in chunks that must not straddle the two sources: materialise torch.cat
+            cat = make(x1->C + x2->C, x1->H, x1->W);
+            if (!rc && !net->dry) {
+                const long total = (long)net->B * cat->C * x1->H * x1->W;
+                int g = cdiv(total, 1024); if (g > 4096) g = 4096;
+                hipLaunchKernelGGL(concat_kernel, dim3(g), dim3(256), 0, net->st, ptr(x1), ptr(x2), wptr(cat), x1->C, x2->C, (long)x1->H * x1->W, total);
+            }
+            x1 = cat;
+            x2 = nullptr;
+        }
         for (size_t i = 0; i < layers.size(); ++i) {
             const Layer &l = layers[i];
             const Tensor *in1 = h ? h : x1;
@@ -639,6 +651,7 @@ struct Fwd {
             if (h) release(h);
             h = o;
         }
+        if (cat) release(cat);
         return h;
     }
 };
@@ -785,5 +798,76 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
     IPDM_HIP_CHECK(hipStreamSynchronize(st));
     (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_g); (void)hipFree(d_be); (void)hipFree(d_sc); (void)hipFree(d_sh);
     (void)hipFree(d_part);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------ micro-benchmark entry
+// Times `iters` launches of one conv configuration on random data (kernel tuning; not on the product path).
+extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, int32_t W, int32_t Cout, int32_t ksize,
+                                 int32_t stride, int32_t act, int32_t with_res, int32_t iters, float *avg_ms)
+{
+    IPDM_REQUIRE(avg_ms && iters > 0, "bench_conv2d: bad argument");
+    const int Cin = C1 + C2, pad = ksize / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    std::vector<float> w((size_t)Cout * Cin * ksize * ksize), packed;
+    for (size_t i = 0; i < w.size(); ++i) w[i] = (float)((i * 2654435761u) % 2001) / 1000.0f - 1.0f;
+    int cin_pad, cout_pad;
+    conv_pack_weights(w.data(), Cout, Cin, ksize, packed, cin_pad, cout_pad);
+    float *d_w, *d_x1, *d_x2 = nullptr, *d_out, *d_res = nullptr, *d_sc, *d_sh, *d_b;
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_w, packed.size() * 4));
+    IPDM_HIP_CHECK(hipMemcpy(d_w, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_x1, (size_t)B * C1 * H * W * 4));
+    ipdm_randn(d_x1, B, (int64_t)C1 * H * W, 1, 0, 0, nullptr);
+    if (C2) { IPDM_HIP_CHECK(hipMalloc((void **)&d_x2, (size_t)B * C2 * H * W * 4)); ipdm_randn(d_x2, B, (int64_t)C2 * H * W, 2, 0, 0, nullptr); }
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_out, (size_t)B * Cout * Ho * Wo * 4));
+    if (with_res) { IPDM_HIP_CHECK(hipMalloc((void **)&d_res, (size_t)B * Cout * Ho * Wo * 4)); ipdm_randn(d_res, B, (int64_t)Cout * Ho * Wo, 3, 0, 0, nullptr); }
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_sc, (size_t)B * Cin * 4));
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_sh, (size_t)B * Cin * 4));
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_b, (size_t)Cout * 4));
+    ipdm_randn(d_sc, 1, (int64_t)B * Cin, 4, 0, 0, nullptr);
+    ipdm_randn(d_sh, 1, (int64_t)B * Cin, 5, 0, 0, nullptr);
+    ipdm_randn(d_b, 1, Cout, 6, 0, 0, nullptr);
+    ConvArgs a;
+    a.x1 = d_x1; a.x2 = d_x2; a.C1 = C1; a.C2 = C2; a.B = B; a.Hs = H; a.Ws = W; a.H = H; a.W = W; a.upsample = 0;
+    a.scale_y = a.scale_x = 1.f; a.w = d_w; a.cout_pad = cout_pad; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
+    a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
+    a.tiles_x = a.tiles_y = a.co_tiles = 0;
+    int rc = 0;
+    for (int i = 0; i < 3 && !rc; ++i) rc = conv2d_launch(a, nullptr);
+    hipEvent_t e0, e1;
+    IPDM_HIP_CHECK(hipEventCreate(&e0));
+    IPDM_HIP_CHECK(hipEventCreate(&e1));
+    IPDM_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && !rc; ++i) rc = conv2d_launch(a, nullptr);
+    IPDM_HIP_CHECK(hipEventRecord(e1, nullptr));
+    IPDM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    IPDM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipFree(d_w); (void)hipFree(d_x1); (void)hipFree(d_x2); (void)hipFree(d_out); (void)hipFree(d_res); (void)hipFree(d_sc);
+    (void)hipFree(d_sh); (void)hipFree(d_b); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
+extern "C" int ipdm_bench_attention(int32_t B, int32_t heads, int32_t d, int32_t T, int32_t iters, float *avg_ms)
+{
+    IPDM_REQUIRE(avg_ms && iters > 0, "bench_attention: bad argument");
+    float *d_qkv, *d_out;
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_qkv, (size_t)B * heads * 3 * d * T * 4));
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_out, (size_t)B * heads * d * T * 4));
+    ipdm_randn(d_qkv, B, (int64_t)heads * 3 * d * T, 9, 0, 0, nullptr);
+    int rc = 0;
+    for (int i = 0; i < 2 && !rc; ++i) rc = attention_launch(d_qkv, d_out, B, heads, d, T, nullptr);
+    hipEvent_t e0, e1;
+    IPDM_HIP_CHECK(hipEventCreate(&e0));
+    IPDM_HIP_CHECK(hipEventCreate(&e1));
+    IPDM_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && !rc; ++i) rc = attention_launch(d_qkv, d_out, B, heads, d, T, nullptr);
+    IPDM_HIP_CHECK(hipEventRecord(e1, nullptr));
+    IPDM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    IPDM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipFree(d_qkv); (void)hipFree(d_out); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
 }

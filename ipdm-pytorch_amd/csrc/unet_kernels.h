@@ -25,6 +25,7 @@ struct ConvArgs {
 };
 
 int conv2d_launch(const ConvArgs &a, hipStream_t st);
+int conv_k_chunk();   // concat inputs must split at a multiple of this many channels
 
 // per-launch HIP-event timing of kernel classes (bench.py roofline): 0 = conv 3x3 s1 wide tile (the
 // dominant kernel), 1 = every other conv variant, 2 = attention
