@@ -13,3 +13,19 @@ from . import _lib  # noqa: F401
 from ._lib import IpdmError, lib  # noqa: F401
 
 __all__ = ["IpdmError", "lib"]
+
+_LAZY = {
+    "progressive_domain_denoiser": "denoiser", "ResultTempDict": "denoiser", "miu2pixel": "denoiser",
+    "default_cfg": "config", "cfg_load": "config",
+    "GaussianDiffusion": "diffusion", "NoiseSource": "diffusion", "InjectedNoise": "diffusion",
+    "UNetModel": "unet", "FBP": "fbp", "tensor_sharpen": "fbp",
+}
+__all__ += list(_LAZY)
+
+
+def __getattr__(name):
+    """The reference's class names at package level (torch is imported only when one is asked for)."""
+    if name in _LAZY:
+        import importlib
+        return getattr(importlib.import_module("." + _LAZY[name], __name__), name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))

@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: libipdm_hip.so loads without a GPU, exports every symbol
+include/ipdm_hip.h declares, the ctypes table in _lib.py covers exactly that set, and the host-only
+entry points (no kernel launch) behave.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ipdm_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ipdm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_path():
+    names = _declared()
+    for must in ("ipdm_fbp_forward", "ipdm_unet_forward", "ipdm_ddpm_step", "ipdm_q_sample", "ipdm_guidance_map",
+                 "ipdm_lambda_ratio", "ipdm_sharpen3x3", "ipdm_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from ipdm_pytorch_amd import _lib
+    assert os.path.isfile(_lib.LIB_PATH), "libipdm_hip.so missing: run __graft_entry__.build()"
+    h = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in _declared() if not hasattr(h, n)]
+    assert not missing, "declared in include/ipdm_hip.h but not exported: %s" % missing
+
+
+def test_ctypes_table_matches_header():
+    from ipdm_pytorch_amd import _lib
+    assert sorted(_lib.PROTOTYPES) == _declared()
+
+
+def test_host_only_entry_points():
+    """Schedule tables and UNet parameter inventory are host code: callable without a GPU."""
+    from ipdm_pytorch_amd import _lib
+    lib = _lib.lib()
+    assert lib.ipdm_abi_version() >= 1
+    out = C.c_double()
+    _lib.call("ipdm_cosine_lambda", 15, 1.0, 3, C.byref(out))
+    assert 0.0 <= out.value <= 0.999
+    cfg = _lib.UnetCfg()
+    cfg.in_channels, cfg.model_channels, cfg.out_channels, cfg.num_res_blocks, cfg.num_heads = 1, 64, 1, 2, 4
+    mult = [1, 1, 2, 2, 4, 4]
+    cfg.n_mult, cfg.n_attn = len(mult), 2
+    for i, m in enumerate(mult):
+        cfg.channel_mult[i] = m
+    cfg.attention_resolutions[0], cfg.attention_resolutions[1] = 8, 16
+    n = lib.ipdm_unet_param_count(C.byref(cfg))
+    assert n > 0
+    total = 0
+    name = C.create_string_buffer(128)
+    shape, nd = (C.c_int32 * 4)(), C.c_int32()
+    for i in range(n):
+        _lib.call("ipdm_unet_param_info", C.byref(cfg), i, name, 128, C.byref(shape), C.byref(nd))
+        k = 1
+        for d in range(nd.value):
+            k *= shape[d]
+        total += k
+    assert total == 29_094_465 or abs(total - 29.09e6) < 0.01e6     # 29.09 M parameters (img net)
+
+
+def test_errors_are_status_codes_not_exceptions():
+    from ipdm_pytorch_amd import _lib
+    lib = _lib.lib()
+    rc = lib.ipdm_unet_param_count(None)
+    assert rc < 0 and lib.ipdm_last_error()
+    with pytest.raises(_lib.IpdmError):
+        _lib.call("ipdm_cosine_lambda", 0, 1.0, 0, C.byref(C.c_double()))

@@ -1,0 +1,73 @@
+"""world_size-2 `gloo` tests of the N>1 path on CPU: contiguous slice sharding, the single end-of-path
+all-gather (equal and ragged shards), max-over-ranks timing, and that sharded per-slice work is
+identical to the unsharded result (the reference has no multi-device path)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _per_slice_work(x, slice_id0):
+    """Stand-in for the per-slice sample: a deterministic function of (global slice id, slice data)."""
+    ids = torch.arange(slice_id0, slice_id0 + x.shape[0], dtype=x.dtype).view(-1, 1, 1, 1)
+    return torch.sin(x * (1.0 + ids)) + ids
+
+
+def _worker(rank, world, port, n_slices, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from ipdm_pytorch_amd import dist as idist
+    r, w, _ = idist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    full = torch.arange(n_slices * 6, dtype=torch.float32).view(n_slices, 1, 2, 3) / 7.0
+    lo, hi = idist.shard_range(n_slices, r, w)
+    local = _per_slice_work(full[lo:hi], lo)
+    out = idist.all_gather_slices(local, n_slices, r, w)
+    want = _per_slice_work(full, 0)
+    t = idist.max_over_ranks(1.0 + rank, "cpu")
+    idist.barrier()
+    q.put((rank, bool(torch.equal(out, want)), tuple(out.shape), t, (lo, hi)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_slices", [4, 5, 1])
+def test_shard_and_all_gather_world2(n_slices):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_slices, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ranges = []
+    for rank, same, shape, t, rng in res:
+        assert same, "rank %d: gathered result differs from the unsharded one" % rank
+        assert shape == (n_slices, 1, 2, 3)
+        assert t == 2.0                       # max over ranks of (1.0, 2.0)
+        ranges.append(rng)
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == n_slices
+
+
+def test_shard_range_partitions():
+    from ipdm_pytorch_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 64):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_range(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            for a, b in zip(cuts, cuts[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
