@@ -25,6 +25,7 @@
 //   operands) and write chunk c+1 to the other LDS buffer, (4) one barrier.  The global-load latency
 //   is therefore hidden behind ~9k cycles of MFMA work.  All LDS operand reads are 32 consecutive
 //   dwords per half-wave (conflict-free ds_read_b32).
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "unet_kernels.h"
@@ -345,6 +346,9 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
     IPDM_REQUIRE(a.C2 == 0 || a.x2, "conv2d: second source missing");
     IPDM_REQUIRE(!a.act || (a.gn_scale && a.gn_shift), "conv2d: GN prologue without scale/shift");
     const bool wide = a.Cout > 32;
+    // wide 3x3 convolutions (>80 % of the path's FLOPs) run on the persistent wave-specialised kernel (conv_ws.hip);
+    // when their weights were packed for it (conv_weight_interleave); IPDM_CONV_LEGACY=1 at pack time keeps them here
+    if (a.w_interleave) return conv2d_ws_launch(a, st);
     if (a.ksize == 3 && a.stride == 1) return wide ? launch_conv<3, 1, 2, 2, 8>(a, st) : launch_conv<3, 1, 1, 2, 8>(a, st);
     if (a.ksize == 3 && a.stride == 2) return wide ? launch_conv<3, 2, 2, 1, 8>(a, st) : launch_conv<3, 2, 1, 1, 8>(a, st);
     if (a.ksize == 1 && a.stride == 1) return wide ? launch_conv<1, 1, 2, 2, 8>(a, st) : launch_conv<1, 1, 1, 2, 8>(a, st);
@@ -354,17 +358,34 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
 
 int conv_k_chunk() { return 8; }
 
-// Repack reference-layout weights [Cout][Cin][k][k] (host) -> [Cin_pad][k*k][Cout_pad] (host), zero padded.
-void conv_pack_weights(const float *w, int Cout, int Cin, int ks, std::vector<float> &packed, int &cin_pad, int &cout_pad)
+int conv_weight_interleave(int Cout, int ks, int stride)
 {
+    static const bool legacy = getenv("IPDM_CONV_LEGACY") != nullptr;
+    if (legacy || ks != 3 || stride != 1 || Cout <= 32) return 0;
+    return Cout > 96 ? 4 : 2;       // 128-cout tiles (MB=4,NB=2) for the wide layers, 64-cout x 16-row tiles (MB=2,NB=4) otherwise
+}
+
+// Repack reference-layout weights [Cout][Cin][k][k] (host) -> [Cin_pad][k*k][Cout_pad] (host), zero padded.
+// interleave = MB > 0: inside every group of 32*MB couts the order is [l = co%32][m = co/32], so that the MB values one
+// MFMA lane needs are adjacent in the LDS slab (one ds_read_b64/b128 per tap in conv_ws.hip).
+void conv_pack_weights(const float *w, int Cout, int Cin, int ks, int interleave, std::vector<float> &packed, int &cin_pad,
+                       int &cout_pad)
+{
+    const int group = interleave ? 32 * interleave : 64;
     cin_pad = (Cin + 7) / 8 * 8;
-    cout_pad = (Cout + 63) / 64 * 64;
+    cout_pad = (Cout + group - 1) / group * group;
     const int taps = ks * ks;
     packed.assign((size_t)cin_pad * taps * cout_pad, 0.0f);
-    for (int co = 0; co < Cout; ++co)
+    for (int co = 0; co < Cout; ++co) {
+        int pos = co;
+        if (interleave) {
+            const int g = co / group, within = co % group;
+            pos = g * group + (within % 32) * interleave + within / 32;
+        }
         for (int ci = 0; ci < Cin; ++ci)
             for (int t = 0; t < taps; ++t)
-                packed[((size_t)ci * taps + t) * cout_pad + co] = w[((size_t)co * Cin + ci) * taps + t];
+                packed[((size_t)ci * taps + t) * cout_pad + pos] = w[((size_t)co * Cin + ci) * taps + t];
+    }
 }
 
 }  // namespace ipdm

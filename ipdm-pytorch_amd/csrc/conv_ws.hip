@@ -1,0 +1,483 @@
+// Persistent, wave-specialised implicit-GEMM convolution for gfx950 (the dominant kernel of the path).
+//
+// Same mathematics and fused prologue/epilogue as conv.hip (nearest up-sampling + channel concat as input
+// addressing, GroupNorm(+SiLU) applied while staging, bias / time-embedding / residual epilogue, exact-f32
+// v_mfma_f32_32x32x2_f32), different execution structure -- chosen from the round-1 counters of conv.hip
+// (profiles/r01b_pmc_sq_*: matrix pipe 73 % busy, both co-resident workgroups parked on the same global-load
+// latency in lockstep):
+//
+//   * one 512-thread workgroup per CU, PERSISTENT over a static round-robin of output tiles;
+//   * waves 0-3 (one per SIMD) are CONSUMERS: nothing but ds_read + MFMA + the tile epilogue.  Their
+//     instruction stream never touches global memory inside the K loop, so the matrix pipe of each SIMD is
+//     fed back-to-back by a single wave whose LDS operands are fetched one tap ahead;
+//   * waves 4-7 (the SIMD partners of 0-3) are PRODUCERS: they issue the global loads of the NEXT K chunk
+//     (which may belong to the next tile), apply GroupNorm/SiLU + zero padding and fill the other LDS
+//     stage while the consumers compute -- VALU/VMEM work co-issues beside the partner's MFMAs;
+//   * one workgroup barrier per K chunk hands the stage over; the chunk stream runs across tile
+//     boundaries, so there is no per-tile prologue bubble and the epilogue stores of tile i drain while
+//     tile i+1 is already being multiplied.
+//
+// Tile = (4*NB rows) x 32 cols of output pixels x (32*MB) couts; consumer wave w owns rows
+// [w*NB,(w+1)*NB).  LDS per stage: input halo tile [KC][IN_ROWS][IN_COLS] + weight slab [KC][taps][32][MB].
+//
+// Issue model measured on MI355X (tools/ubench/coissue.hip): v_mfma_f32_32x32x2_f32 holds its OWN wave's issue
+// for the full 64 cycles (every ds_read / s_waitcnt / VALU op of the consumer is additive, ~9 cycles), while the
+// partner wave on the SIMD issues beside it at ~25 cycles per VALU op and 16 per ds_write without slowing the MFMA
+// stream.  Hence: (i) big register tiles (MB*NB = 8 accumulators) and ONE wide LDS read per tap for the weights
+// (the slab is stored cout-interleaved so the MB values of a lane are adjacent: ds_read_b64/b128) keep the
+// consumer at ~0.2 LDS instructions per MFMA; (ii) a chunk carries 18k cycles of MFMA work, twice what the
+// producers need for their ~250 slow-issuing instructions plus one global-load latency.
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+#include "unet_kernels.h"
+
+using namespace ipdm;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+template <int KS, int STRIDE, int MB, int NB, int KC_>
+struct WsTile {
+    static constexpr int KC = KC_;
+    static constexpr int TAPS = KS * KS;
+    static constexpr int TH = 4 * NB;
+    static constexpr int TW = 32;
+    static constexpr int IN_ROWS = (TH - 1) * STRIDE + KS;
+    static constexpr int IN_COLS = (TW - 1) * STRIDE + KS;
+    static constexpr int IN_CH = IN_ROWS * IN_COLS;
+    static constexpr int SP = (IN_CH + 255) / 256;           // staging slots per producer thread per channel
+    static constexpr int IN_CHP = SP * 256;                  // LDS channel pitch: every (thread, slot) owns an address
+    static constexpr int IN_TILE = KC * IN_CHP;
+    static constexpr int BN = 32 * MB;
+    static constexpr int W_TILE = KC * TAPS * BN;
+    static constexpr int W_VEC = (W_TILE / 4 + 255) / 256;   // 16-byte weight loads per producer thread per chunk
+    static constexpr int W_TILEP = W_VEC * 256 * 4;
+    static constexpr int BUF = IN_TILE + W_TILEP;
+    static constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(float);
+};
+
+struct TileId { int n, oy0, ox0, co0; };
+
+template <int TH, int TW, int BN>
+__device__ inline TileId decode_tile(const ConvArgs &a, int tile)
+{
+    TileId t;
+    const int co_t = tile % a.co_tiles;
+    int rest = tile / a.co_tiles;
+    const int tx = rest % a.tiles_x;
+    rest /= a.tiles_x;
+    const int ty = rest % a.tiles_y;
+    t.n = rest / a.tiles_y;
+    t.oy0 = ty * TH;
+    t.ox0 = tx * TW;
+    t.co0 = co_t * BN;
+    return t;
+}
+
+// Per-lane (VGPR) buffer offset that is out of range: loads return 0 and stores are dropped, no branch.  The hardware
+// compares the VGPR offset with (num_records - scalar offset), so the SCALAR offset must always stay inside the buffer:
+// invalid elements are always killed through the per-lane offset, never through the scalar one.
+constexpr int OOB = 0x7fffffff;
+
+__device__ inline float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+// SiLU(x*sc+sh) on a pair: 3 packed VALU + 2 exp + 2 rcp (the producers get ~1 VALU issue per partner MFMA)
+__device__ inline f32x2 gn_silu2(f32x2 x, float sc, float sh)
+{
+    f32x2 z = x * sc + sh;
+    f32x2 e = z * -1.4426950408889634f;
+    e[0] = __builtin_amdgcn_exp2f(e[0]);
+    e[1] = __builtin_amdgcn_exp2f(e[1]);
+    e = e + 1.0f;
+    e[0] = __builtin_amdgcn_rcpf(e[0]);
+    e[1] = __builtin_amdgcn_rcpf(e[1]);
+    return z * e;
+}
+
+template <int KS, int STRIDE, int MB, int NB, int KC>
+__global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
+{
+    using T = WsTile<KS, STRIDE, MB, NB, KC>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    // ---- static tile schedule: at step k the G workgroups cover tiles [kG,(k+1)G); the workgroups of one XCD
+    //      (blockIdx % 8) take a contiguous run of them, so the cout tiles / halo neighbours that re-read the
+    //      same input share that XCD's L2.
+    //      The slot is rotated by 5 every round: with a fixed slot a workgroup would see the same tile column every
+    //      round (G is a multiple of tiles_x for the usual sizes) and the ones on the ragged right edge would only
+    //      ever get partial tiles.
+    const int G = gridDim.x, per = G >> 3;
+    const int local = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int rounds = (ntiles + G - 1) / G;
+    auto tile_of = [&](int k) { return k * G + (local + 5 * k) % G; };
+    const int n_my = rounds == 0 ? 0 : (tile_of(rounds - 1) < ntiles ? rounds : rounds - 1);
+    const int Ctot = a.C1 + a.C2;
+    const int nchunks = (Ctot + KC - 1) / KC;
+    const int S = n_my * nchunks;                  // chunks in this workgroup's stream
+    const int plane_bytes = a.Hs * a.Ws * 4;
+
+    // De-phase the workgroups: identical tiles keep all 256 CUs in lockstep, so every CU would burst its tile's
+    // stores (32-131 KB) at the same instant and the consumers would sit on a full store queue at HBM speed.
+    if (a.dbg >> 8) {
+        const int phase = (a.dbg & 32) ? (blockIdx.x & 7) : ((blockIdx.x >> 3) & 7);
+        for (int i = 0; i < phase * (a.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    if (threadIdx.x >= 256) {
+        // =========================================================================== PRODUCERS
+        // Addressing is VALU-free: buffer loads take a per-thread byte offset that is constant for a tile (input) or
+        // for the whole kernel (weights) plus a scalar offset per channel / chunk; out-of-range offsets read 0.
+        const int tid = threadIdx.x - 256;
+        int w_voff[T::W_VEC];
+#pragma unroll
+        for (int e = 0; e < T::W_VEC; ++e) {
+            const int v4 = tid + e * 256;
+            const int row = v4 / (T::BN / 4), col4 = v4 % (T::BN / 4);
+            w_voff[e] = v4 < T::W_TILE / 4 ? (row * a.cout_pad + col4 * 4) * 4 : OOB;
+        }
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)a.w, 0, ((Ctot + 7) / 8 * 8) * T::TAPS * a.cout_pad * 4, 0x00020000);
+        int in_voff[T::SP];
+        bool in_ok[T::SP];
+        TileId t = {0, 0, 0, 0};
+        bool border = false;
+        const bool pstamp = (a.dbg & 8) != 0;
+        unsigned long long p_issue = 0, p_wait = 0, p_math = 0, p_store = 0, p_t = 0;
+        for (int s = 0; s < S; ++s) {
+            if (pstamp) p_t = __builtin_amdgcn_s_memtime();
+            {
+                const int k = s / nchunks, ch = s - k * nchunks;
+                if (ch == 0) {      // new tile: spatial descriptors (the same for every channel chunk of the tile)
+                    t = decode_tile<T::TH, T::TW, T::BN>(a, tile_of(k));
+                    const int iy0 = t.oy0 * STRIDE - KS / 2, ix0 = t.ox0 * STRIDE - KS / 2;
+                    border = iy0 < 0 || ix0 < 0 || iy0 + T::IN_ROWS > a.H || ix0 + T::IN_COLS > a.W;
+#pragma unroll
+                    for (int j = 0; j < T::SP; ++j) {
+                        const int sp = tid + j * 256;
+                        const int r = sp / T::IN_COLS, c = sp % T::IN_COLS;
+                        const int iy = iy0 + r, ix = ix0 + c;
+                        in_ok[j] = sp < T::IN_CH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                        int sy = min(max(iy, 0), a.H - 1), sx = min(max(ix, 0), a.W - 1);
+                        if (a.upsample) {   // F.interpolate(mode="nearest"): src = min(floor(dst * (in/out) in f32), in-1)
+                            sy = min((int)floorf((float)sy * a.scale_y), a.Hs - 1);
+                            sx = min((int)floorf((float)sx * a.scale_x), a.Ws - 1);
+                        }
+                        in_voff[j] = in_ok[j] ? (sy * a.Ws + sx) * 4 : OOB;      // padding / idle slots read 0
+                    }
+                }
+                const int c0 = ch * KC;
+                const int nvalid = min(KC, Ctot - c0);
+                float *ib = lds + (s & 1) * T::BUF;
+                // a chunk never straddles the two concatenated sources (launcher: C1 % KC == 0 when C2 > 0)
+                const bool from1 = c0 < a.C1;
+                const int csrc = from1 ? a.C1 : a.C2;
+                const float *src = from1 ? a.x1 + (size_t)t.n * a.C1 * (plane_bytes / 4)
+                                         : a.x2 + (size_t)t.n * a.C2 * (plane_bytes / 4);
+                const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, csrc * plane_bytes, 0x00020000);
+                const int cs0 = from1 ? c0 : c0 - a.C1;
+                // weights first (they need no transform and go to LDS as soon as they land), then the raw input tile
+                f32x4 w_reg[T::W_VEC];
+                const int w_soff = (c0 * T::TAPS * a.cout_pad + t.co0) * 4;
+#pragma unroll
+                for (int e = 0; e < T::W_VEC; ++e)
+                    w_reg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[e], w_soff, 0));
+                float raw[KC][T::SP];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    // channels beyond Cin re-read the last real channel (in-range scalar offset); their weights are zero
+                    const int soff = (cs0 + min(c, nvalid - 1)) * plane_bytes;
+#pragma unroll
+                    for (int j = 0; j < T::SP; ++j) raw[c][j] = bload(x_rsrc, in_voff[j], soff);
+                }
+                // stage (s&1) was last read by chunk s-2, which the consumers finished before the previous hand-over
+#pragma unroll
+                for (int e = 0; e < T::W_VEC; ++e)
+                    *reinterpret_cast<f32x4 *>(ib + T::IN_TILE + (tid + e * 256) * 4) = w_reg[e];
+                if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_issue += now - p_t; p_t = now; }
+                float *dst = ib + tid;
+                if (a.act) {
+                    // GroupNorm(+SiLU) of the staged values.  The f32 MFMA executes on the SIMD's vector ALU: while the
+                    // partner wave streams MFMAs this wave's VALU only gets the partner's stall gaps (measured ~280
+                    // cycles per op, any priority).  So the transform runs as a burst inside a window in which the
+                    // consumers wait (barrier A .. hand-over barrier): ~100 VALU ops at full rate instead of a whole
+                    // chunk time of starvation.
+                    const float *gsc = a.gn_scale + (size_t)t.n * Ctot + c0, *gsh = a.gn_shift + (size_t)t.n * Ctot + c0;
+                    float scv[KC], shv[KC];
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) {
+                        scv[c] = c < nvalid ? gsc[c] : 0.0f;
+                        shv[c] = c < nvalid ? gsh[c] : 0.0f;
+                    }
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_wait += now - p_t; p_t = now; }
+                    __syncthreads();                       // A: consumers have finished chunk s-1
+                    if (pstamp) p_t = __builtin_amdgcn_s_memtime();
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) {
+                        const float sc = scv[c], sh = shv[c];
+#pragma unroll
+                        for (int j = 0; j + 1 < T::SP; j += 2) {
+                            f32x2 v = {raw[c][j], raw[c][j + 1]};
+                            v = a.act == 2 ? gn_silu2(v, sc, sh) : v * sc + sh;
+                            raw[c][j] = v[0];
+                            raw[c][j + 1] = v[1];
+                        }
+                        if (T::SP & 1) {
+                            f32x2 v = {raw[c][T::SP - 1], 0.0f};
+                            v = a.act == 2 ? gn_silu2(v, sc, sh) : v * sc + sh;
+                            raw[c][T::SP - 1] = v[0];
+                        }
+                    }
+                    if (border) {      // zero padding is re-imposed AFTER the activation (border tiles only)
+#pragma unroll
+                        for (int c = 0; c < KC; ++c)
+#pragma unroll
+                            for (int j = 0; j < T::SP; ++j) raw[c][j] = in_ok[j] ? raw[c][j] : 0.0f;
+                    }
+                    if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_math += now - p_t; p_t = now; }
+                }
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int j = 0; j < T::SP; ++j) dst[c * T::IN_CHP + j * 256] = raw[c][j];
+                if (pstamp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                              const unsigned long long now = __builtin_amdgcn_s_memtime(); p_store += now - p_t; p_t = now; }
+                __syncthreads();                           // hand-over: stage (s&1) is complete
+            }
+        }
+        if (pstamp && tid == 0) {
+            unsigned long long *d = a.dbg_buf + (size_t)blockIdx.x * 8 + 4;
+            d[0] = p_issue; d[1] = p_wait; d[2] = p_math; d[3] = p_store;
+        }
+        return;
+    }
+
+    // =============================================================================== CONSUMERS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lk = lane >> 5, l31 = lane & 31;
+    constexpr int ROWS = (NB - 1) * STRIDE + KS;
+    constexpr int NP = KC / 2;
+
+    f32x16 acc[MB][NB];
+    unsigned long long t_mma = 0, t_epi = 0, t_bar = 0, t_last = 0;
+    const bool stamp = (a.dbg & 8) != 0;
+    const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    t_last = t_begin;
+    // Epilogue addressing is VALU-free: buffer stores take ONE per-lane byte offset (fixed for the whole kernel) and a
+    // scalar offset per (cout, row); anything outside the sample's [Cout][Ho][Wo] block is dropped by the range check.
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const int out_plane = a.Ho * a.Wo;
+    const int lane_off = (lk * 4 * out_plane + l31) * 4;
+    // bias (conv bias + time-embedding projection) enters as the accumulators' initial value through one MFMA per
+    // accumulator (A = bias of the lane's cout on the k=0 half, B = 1): no per-element add in the epilogue.  The MB bias
+    // values of the NEXT tile are fetched while the current tile's last chunk is multiplied.
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
+    float nb[MB];
+    auto fetch_bias = [&](int k) __attribute__((always_inline)) {
+        const TileId t = decode_tile<T::TH, T::TW, T::BN>(a, tile_of(k));
+#pragma unroll
+        for (int m = 0; m < MB; ++m) nb[m] = bload(b_rsrc, lk ? OOB : l31 * 4, min(t.co0 + m * 32, a.Cout - 1) * 4);
+    };
+    if (S > 0) fetch_bias(0);
+    for (int s = 0; s < S; ++s) {
+        if (a.act) __syncthreads();                // A: chunk s-1 done -> the producers' transform burst may use the SIMD
+        __syncthreads();                           // hand-over: stage (s&1) is complete
+        if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_bar += now - t_last; t_last = now; }
+        const int k = s / nchunks, ch = s - k * nchunks;
+        if (ch == 0) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int q = 0; q < NB; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[m], 1.0f, zero, 0, 0, 0);
+        }
+        if (ch == nchunks - 1 && k + 1 < n_my) fetch_bias(k + 1);
+        const float *ib = lds + (s & 1) * T::BUF;
+        const float *wb = ib + T::IN_TILE;
+        {
+            // operands: B = the ROWS x KS input values of one channel pair this wave touches (fetched one pair
+            // ahead), A = the MB weight values of one tap (fetched one tap ahead); channels beyond Cin are zero
+            // in LDS (producer padding), so every chunk runs the full schedule.
+            float b_cur[ROWS][KS], b_nxt[ROWS][KS], a_c[MB], a_n[MB];
+            auto read_b = [&](int cp, float (&Bv)[ROWS][KS]) __attribute__((always_inline)) {
+                const int c = cp * 2 + lk;
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx)
+                        Bv[r][kx] = ib[c * T::IN_CHP + (wave * NB * STRIDE + r) * T::IN_COLS + l31 * STRIDE + kx];
+            };
+            auto read_a = [&](int cp, int t, float (&A)[MB]) __attribute__((always_inline)) {
+                const int c = cp * 2 + lk;
+                typedef float fvec __attribute__((ext_vector_type(MB)));
+                const fvec v = *reinterpret_cast<const fvec *>(wb + ((c * T::TAPS + t) * 32 + l31) * MB);   // [c][tap][l31][m]
+#pragma unroll
+                for (int m = 0; m < MB; ++m) A[m] = v[m];
+            };
+            read_b(0, b_cur);
+            read_a(0, 0, a_c);
+#pragma unroll
+            for (int cp = 0; cp < NP; ++cp) {
+                if (cp + 1 < NP) read_b(cp + 1, b_nxt);
+#pragma unroll
+                for (int t = 0; t < T::TAPS; ++t) {
+                    if (t + 1 < T::TAPS) read_a(cp, t + 1, a_n);
+                    else if (cp + 1 < NP) read_a(cp + 1, 0, a_n);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int q = 0; q < NB; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[m], b_cur[q * STRIDE + t / KS][t % KS], acc[m][q], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) a_c[m] = a_n[m];
+                }
+                if (cp + 1 < NP) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                        for (int kx = 0; kx < KS; ++kx) b_cur[r][kx] = b_nxt[r][kx];
+                }
+            }
+        }
+        if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_mma += now - t_last; t_last = now; }
+        if (ch == nchunks - 1) {
+            // ---- tile epilogue: (+ residual) -> NCHW stores, 32 consecutive pixels per half-wave; the stores drain
+            //      while the next tile is multiplied
+            const TileId t = decode_tile<T::TH, T::TW, T::BN>(a, tile_of(k));
+            const size_t sample = (size_t)t.n * a.Cout * out_plane;
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * out_plane * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0, a.Cout * out_plane * 4, 0x00020000);
+            // per-lane offset: lane part, or out of range for columns beyond Wo / rows beyond Ho (dropped by the range
+            // check); scalar offset: pure adds -- cout of register r is co0 + 32m + (r&3) + 8(r>>2) [+ 4 lk in lane_off]
+            const int plane4 = out_plane * 4;
+            int voffq[NB], rowq[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int oy = t.oy0 + swave * NB + q;
+                voffq[q] = (t.ox0 + l31 < a.Wo && oy < a.Ho) ? lane_off : OOB;
+                rowq[q] = (min(oy, a.Ho - 1) * a.Wo + t.ox0) * 4;     // scalar offsets stay in range; the lanes are killed above
+            }
+            // PARTIAL: the tile's couts run past Cout (Cout % (32*MB) != 0): those registers are skipped by a scalar
+            // branch (their scalar offset would leave the buffer); full tiles carry no such test.
+            auto epilogue = [&](auto partial_tag) __attribute__((always_inline)) {
+                constexpr bool PARTIAL = decltype(partial_tag)::value;
+                auto co_ok = [&](int m, int r) { return !PARTIAL || t.co0 + m * 32 + (r & 3) + 8 * (r >> 2) < a.Cout; };
+                if (a.res) {
+                    // residual first, as its own phase (loads two groups deep): VMEM loads and stores retire through one
+                    // in-order counter, so a load issued behind stores would wait for those stores to reach memory
+                    float rv[2][16];
+                    auto load_group = [&](int m, int q, float (&dst)[16]) __attribute__((always_inline)) {
+                        int so = (t.co0 + m * 32) * plane4 + rowq[q];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            dst[r] = co_ok(m, r) ? bload(r_rsrc, voffq[q], so) : 0.0f;
+                            so += ((r & 3) == 3 ? 5 : 1) * plane4;
+                        }
+                    };
+                    load_group(0, 0, rv[0]);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int q = 0; q < NB; ++q) {
+                            const int idx = m * NB + q;
+                            if (idx + 1 < MB * NB) load_group((idx + 1) / NB, (idx + 1) % NB, rv[(idx + 1) & 1]);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[m][q][r] += rv[idx & 1][r];
+                        }
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        int so = (t.co0 + m * 32) * plane4 + rowq[q];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = acc[m][q][r];      // (bit_cast straight from the vector element stores element 0)
+                            if (co_ok(m, r)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, voffq[q], so, 0);
+                            so += ((r & 3) == 3 ? 5 : 1) * plane4;
+                        }
+                    }
+            };
+            if (t.co0 + T::BN <= a.Cout) epilogue(std::false_type{});
+            else epilogue(std::true_type{});
+        }
+        if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_epi += now - t_last; t_last = now; }
+    }
+    if (stamp && tid == 0) {
+        unsigned long long *d = a.dbg_buf + (size_t)blockIdx.x * 8;
+        d[0] = t_mma; d[1] = t_epi; d[2] = t_bar; d[3] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+}
+
+int num_cus()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
+template <int KS, int STRIDE, int MB, int NB, int KC>
+int launch_ws(const ConvArgs &args, hipStream_t st, int prof_cls)
+{
+    using T = WsTile<KS, STRIDE, MB, NB, KC>;
+    static_assert(T::LDS_BYTES <= 160 * 1024, "conv_ws: LDS stages exceed 160 KiB");
+    ConvArgs a = args;
+    static const int dbg = getenv("IPDM_CONV_DBG") ? atoi(getenv("IPDM_CONV_DBG")) : 0;
+    a.dbg = dbg;
+    a.tiles_x = cdiv(a.Wo, T::TW);
+    a.tiles_y = cdiv(a.Ho, T::TH);
+    a.co_tiles = cdiv(a.Cout, T::BN);
+    IPDM_REQUIRE(a.C2 == 0 || a.C1 % KC == 0, "conv2d: concat split %d not a multiple of the K chunk %d", a.C1, KC);
+    IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29) &&
+                     (long)a.Cout * a.Ho * a.Wo < (1L << 29) &&
+                     (long)((a.C1 + a.C2 + 7) / 8 * 8) * T::TAPS * a.cout_pad < (1L << 29),
+                 "conv2d: per-sample tensor exceeds the 2 GiB buffer-addressing range");
+    const long ntiles = (long)a.tiles_x * a.tiles_y * a.co_tiles * a.B;
+    IPDM_REQUIRE(ntiles < (1L << 31), "conv2d: too many tiles");
+    const int cus = num_cus();
+    int G = (int)(ntiles < cus ? ntiles : cus);
+    G = (G + 7) / 8 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
+        attr_set = true;
+    }
+    const bool prof = prof_enabled();
+    if (prof) prof_before(prof_cls, st);
+    hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC>), dim3((unsigned)G), dim3(512), T::LDS_BYTES, st, a, (int)ntiles);
+    if (prof) prof_after(prof_cls, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+}  // namespace
+
+namespace ipdm {
+
+// 3x3 stride-1 convolutions with more than 32 output channels (weights packed cout-interleaved, see
+// conv_weight_interleave / conv_pack_weights).
+int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
+{
+    if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 4) return launch_ws<3, 1, 4, 2, 8>(a, st, 0);
+    if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 2) return launch_ws<3, 1, 2, 4, 8>(a, st, 0);
+    set_error("conv2d_ws: unsupported ksize=%d stride=%d interleave=%d", a.ksize, a.stride, a.w_interleave);
+    return IPDM_ERR_UNSUPPORTED;
+}
+
+}  // namespace ipdm

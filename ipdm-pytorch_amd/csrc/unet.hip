@@ -9,6 +9,7 @@
 // Activations are NCHW fp32; the workspace is carved by a first-fit arena whose schedule is replayed
 // identically on every call (ipdm_unet_workspace_bytes runs the same walk without launching).
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -287,7 +288,7 @@ extern "C" int ipdm_unet_param_info(const ipdm_unet_cfg *cfg, int32_t idx, char 
 // ------------------------------------------------------------------------------------ the net
 namespace {
 
-struct ConvP { float *w = nullptr; float *b = nullptr; int cin = 0, cout = 0, ks = 0, cout_pad = 0; };
+struct ConvP { float *w = nullptr; float *b = nullptr; int cin = 0, cout = 0, ks = 0, cout_pad = 0, interleave = 0; };
 struct NormP { float *g = nullptr, *b = nullptr; int ch = 0, groups = 0; };
 struct ResP { NormP n1, n2; ConvP c1, c2, sc; bool has_sc = false; int bias_off = 0; };   // bias_off into bias_eff
 struct AttnP { NormP n; ConvP qkv, proj; };
@@ -380,13 +381,14 @@ struct WeightMap {
 };
 
 int make_conv(ipdm_unet *net, const WeightMap &wm, const std::string &wname, const std::string &bname, int cout, int cin,
-              int ks, ConvP &out)
+              int ks, ConvP &out, int stride = 1)
 {
     const float *w = wm.get(wname);
     IPDM_REQUIRE(w, "unet_create: missing parameter %s", wname.c_str());
     std::vector<float> packed;
     int cin_pad, cout_pad;
-    conv_pack_weights(w, cout, cin, ks, packed, cin_pad, cout_pad);
+    out.interleave = conv_weight_interleave(cout, ks, stride);
+    conv_pack_weights(w, cout, cin, ks, out.interleave, packed, cin_pad, cout_pad);
     out.cin = cin; out.cout = cout; out.ks = ks; out.cout_pad = cout_pad;
     int rc = upload(net, packed.data(), packed.size(), &out.w);
     if (rc) return rc;
@@ -455,7 +457,7 @@ extern "C" int ipdm_unet_create(const ipdm_unet_cfg *cfg, const float *const *we
         int r = 0;
         switch (l.kind) {
             case L_CONV: r = make_conv(net, wm, p + ".weight", p + ".bias", l.cout, l.cin, 3, net->convs[p]); break;
-            case L_DOWN: r = make_conv(net, wm, p + ".op.weight", p + ".op.bias", l.cout, l.cin, 3, net->convs[p]); break;
+            case L_DOWN: r = make_conv(net, wm, p + ".op.weight", p + ".op.bias", l.cout, l.cin, 3, net->convs[p], 2); break;
             case L_UP: r = make_conv(net, wm, p + ".conv.weight", p + ".conv.bias", l.cout, l.cin, 3, net->convs[p]); break;
             case L_RES: {
                 ResP &rp = net->res[p];
@@ -569,7 +571,7 @@ struct Fwd {
         a.Hs = x1->H; a.Ws = x1->W; a.H = H; a.W = W;
         a.upsample = (H != x1->H || W != x1->W);
         a.scale_y = (float)x1->H / (float)H; a.scale_x = (float)x1->W / (float)W;
-        a.w = cp.w; a.cout_pad = cp.cout_pad; a.bias = bias; a.Cout = cp.cout; a.ksize = cp.ks; a.stride = stride;
+        a.w = cp.w; a.cout_pad = cp.cout_pad; a.w_interleave = cp.interleave; a.bias = bias; a.Cout = cp.cout; a.ksize = cp.ks; a.stride = stride;
         a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = net->gn_scale; a.gn_shift = net->gn_shift;
         a.res = res ? ptr(res) : nullptr;
         a.out = ext_out ? ext_out : wptr(o);
@@ -759,7 +761,8 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
     const int Cin = C1 + C2;
     std::vector<float> packed;
     int cin_pad, cout_pad;
-    conv_pack_weights(w_host, Cout, Cin, ksize, packed, cin_pad, cout_pad);
+    const int interleave = conv_weight_interleave(Cout, ksize, stride);
+    conv_pack_weights(w_host, Cout, Cin, ksize, interleave, packed, cin_pad, cout_pad);
     float *d_w = nullptr, *d_b = nullptr, *d_g = nullptr, *d_be = nullptr, *d_sc = nullptr, *d_sh = nullptr;
     double *d_part = nullptr;
     IPDM_HIP_CHECK(hipMalloc((void **)&d_w, packed.size() * sizeof(float)));
@@ -789,7 +792,7 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
         a.x1 = d_x1; a.x2 = d_x2; a.C1 = C1; a.C2 = C2; a.B = B; a.Hs = Hs; a.Ws = Ws; a.H = H; a.W = W;
         a.upsample = (H != Hs || W != Ws);
         a.scale_y = (float)Hs / (float)H; a.scale_x = (float)Ws / (float)W;
-        a.w = d_w; a.cout_pad = cout_pad; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
+        a.w = d_w; a.cout_pad = cout_pad; a.w_interleave = interleave; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
         a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
         a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
         a.tiles_x = a.tiles_y = a.co_tiles = 0;
@@ -812,7 +815,8 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     std::vector<float> w((size_t)Cout * Cin * ksize * ksize), packed;
     for (size_t i = 0; i < w.size(); ++i) w[i] = (float)((i * 2654435761u) % 2001) / 1000.0f - 1.0f;
     int cin_pad, cout_pad;
-    conv_pack_weights(w.data(), Cout, Cin, ksize, packed, cin_pad, cout_pad);
+    const int interleave = conv_weight_interleave(Cout, ksize, stride);
+    conv_pack_weights(w.data(), Cout, Cin, ksize, interleave, packed, cin_pad, cout_pad);
     float *d_w, *d_x1, *d_x2 = nullptr, *d_out, *d_res = nullptr, *d_sc, *d_sh, *d_b;
     IPDM_HIP_CHECK(hipMalloc((void **)&d_w, packed.size() * 4));
     IPDM_HIP_CHECK(hipMemcpy(d_w, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
@@ -829,10 +833,12 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     ipdm_randn(d_b, 1, Cout, 6, 0, 0, nullptr);
     ConvArgs a;
     a.x1 = d_x1; a.x2 = d_x2; a.C1 = C1; a.C2 = C2; a.B = B; a.Hs = H; a.Ws = W; a.H = H; a.W = W; a.upsample = 0;
-    a.scale_y = a.scale_x = 1.f; a.w = d_w; a.cout_pad = cout_pad; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
+    a.scale_y = a.scale_x = 1.f; a.w = d_w; a.cout_pad = cout_pad; a.w_interleave = interleave; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
     a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
     a.tiles_x = a.tiles_y = a.co_tiles = 0;
     int rc = 0;
+    const bool stamps = getenv("IPDM_CONV_DBG") && (atoi(getenv("IPDM_CONV_DBG")) & 8);
+    if (stamps) { IPDM_HIP_CHECK(hipMalloc((void **)&a.dbg_buf, 4096 * 8 * 8)); IPDM_HIP_CHECK(hipMemset(a.dbg_buf, 0, 4096 * 8 * 8)); }
     for (int i = 0; i < 3 && !rc; ++i) rc = conv2d_launch(a, nullptr);
     hipEvent_t e0, e1;
     IPDM_HIP_CHECK(hipEventCreate(&e0));
@@ -844,6 +850,16 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     float ms = 0;
     IPDM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = ms / iters;
+    if (stamps) {   // consumer wave 0 of every workgroup: cycles in MFMA section / epilogue / barrier wait / total (last launch)
+        std::vector<unsigned long long> h(4096 * 8);
+        IPDM_HIP_CHECK(hipMemcpy(h.data(), a.dbg_buf, h.size() * 8, hipMemcpyDeviceToHost));
+        double s4[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nz = 0;
+        for (int g = 0; g < 4096; ++g) if (h[g * 8 + 3]) { for (int k = 0; k < 8; ++k) s4[k] += (double)h[g * 8 + k]; ++nz; }
+        if (nz) fprintf(stderr, "  stamps over %d workgroups (s_memtime ticks, avg): consumer mfma %.0f epilogue %.0f barrier %.0f total %.0f | "
+                        "producer issue %.0f wait %.0f math %.0f store %.0f\n", nz, s4[0] / nz, s4[1] / nz, s4[2] / nz, s4[3] / nz,
+                        s4[4] / nz, s4[5] / nz, s4[6] / nz, s4[7] / nz);
+        (void)hipFree(a.dbg_buf);
+    }
     (void)hipFree(d_w); (void)hipFree(d_x1); (void)hipFree(d_x2); (void)hipFree(d_out); (void)hipFree(d_res); (void)hipFree(d_sc);
     (void)hipFree(d_sh); (void)hipFree(d_b); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;

@@ -14,6 +14,7 @@ struct ConvArgs {
     float scale_y, scale_x;      // Hs/H, Ws/W in float32 (ATen's nearest rule)
     const float *w;              // packed [Cin_pad][k*k][cout_pad]
     int cout_pad;
+    int w_interleave = 0;        // weight-slab layout chosen at pack time: 0 plain [cout], MB>0: cout-interleaved [32][MB] per 32*MB group
     const float *bias;           // [Cout] or null
     int Cout, ksize, stride;
     int Ho, Wo;
@@ -22,9 +23,12 @@ struct ConvArgs {
     const float *res;            // [B,Cout,Ho,Wo] or null
     float *out;
     int tiles_x, tiles_y, co_tiles;     // filled by the launcher
+    int dbg = 0;                        // IPDM_CONV_DBG bit mask (kernel experiments only; 0 on the product path)
+    unsigned long long *dbg_buf = nullptr;   // dbg & 8: per-workgroup cycle stamps [grid][4]
 };
 
 int conv2d_launch(const ConvArgs &a, hipStream_t st);
+int conv2d_ws_launch(const ConvArgs &a, hipStream_t st);   // persistent wave-specialised variant (conv_ws.hip)
 int conv_k_chunk();   // concat inputs must split at a multiple of this many channels
 
 // per-launch HIP-event timing of kernel classes (bench.py roofline): 0 = conv 3x3 s1 wide tile (the
@@ -33,7 +37,9 @@ constexpr int PROF_CLASSES = 3;
 bool prof_enabled();
 void prof_before(int cls, hipStream_t st);
 void prof_after(int cls, double flops, hipStream_t st);
-void conv_pack_weights(const float *w, int Cout, int Cin, int ks, std::vector<float> &packed, int &cin_pad, int &cout_pad);
+// which weight layout / kernel family a convolution of this shape uses (0 = plain layout, legacy kernels of conv.hip)
+int conv_weight_interleave(int Cout, int ks, int stride);
+void conv_pack_weights(const float *w, int Cout, int Cin, int ks, int interleave, std::vector<float> &packed, int &cin_pad, int &cout_pad);
 
 // GroupNorm statistics over (possibly concatenated) NCHW sources -> per-(sample,channel) affine
 // scale/shift: y = x*scale + shift == gamma*(x-mean)*rstd + beta.
