@@ -274,9 +274,8 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     const int out_plane = a.Ho * a.Wo;
     const int lane_off = (lk * 4 * out_plane + l31) * 4;
-    // bias (conv bias + time-embedding projection) enters as the accumulators' initial value through one MFMA per
-    // accumulator (A = bias of the lane's cout on the k=0 half, B = 1): no per-element add in the epilogue.  The MB bias
-    // values of the NEXT tile are fetched while the current tile's last chunk is multiplied.
+    // bias (conv bias + time-embedding projection) is added by one MFMA per accumulator after the last K chunk; the MB
+    // bias values of the NEXT tile are fetched right after, a whole tile ahead of their use.
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
     float nb[MB];
     auto fetch_bias = [&](int k) __attribute__((always_inline)) {
@@ -291,13 +290,13 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
         if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_bar += now - t_last; t_last = now; }
         const int k = s / nchunks, ch = s - k * nchunks;
         if (ch == 0) {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int q = 0; q < NB; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[m], 1.0f, zero, 0, 0, 0);
+                for (int q = 0; q < NB; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.0f;
         }
-        if (ch == nchunks - 1 && k + 1 < n_my) fetch_bias(k + 1);
         const float *ib = lds + (s & 1) * T::BUF;
         const float *wb = ib + T::IN_TILE;
         {
@@ -346,6 +345,15 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                         for (int kx = 0; kx < KS; ++kx) b_cur[r][kx] = b_nxt[r][kx];
                 }
             }
+        }
+        if (ch == nchunks - 1) {
+            // + bias, added LAST as the reference does (conv, then bias): one more MFMA per accumulator with A = the bias
+            // of the lane's cout on the k=0 half and B = 1 -- no per-element VALU add
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int q = 0; q < NB; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[m], 1.0f, acc[m][q], 0, 0, 0);
+            if (k + 1 < n_my) fetch_bias(k + 1);
         }
         if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_mma += now - t_last; t_last = now; }
         if (ch == nchunks - 1) {
