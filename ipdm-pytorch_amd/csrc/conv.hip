@@ -349,6 +349,8 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
     // wide 3x3 convolutions (>80 % of the path's FLOPs) run on the persistent wave-specialised kernel (conv_ws.hip);
     // when their weights were packed for it (conv_weight_interleave); IPDM_CONV_LEGACY=1 at pack time keeps them here
     if (a.w_interleave) return conv2d_ws_launch(a, st);
+    static const bool no_direct = getenv("IPDM_CONV_NO_DIRECT") != nullptr;
+    if (!no_direct && conv_direct_eligible(a)) return conv2d_direct_launch(a, st);
     if (a.ksize == 3 && a.stride == 1) return wide ? launch_conv<3, 1, 2, 2, 8>(a, st) : launch_conv<3, 1, 1, 2, 8>(a, st);
     if (a.ksize == 3 && a.stride == 2) return wide ? launch_conv<3, 2, 2, 1, 8>(a, st) : launch_conv<3, 2, 1, 1, 8>(a, st);
     if (a.ksize == 1 && a.stride == 1) return wide ? launch_conv<1, 1, 2, 2, 8>(a, st) : launch_conv<1, 1, 1, 2, 8>(a, st);

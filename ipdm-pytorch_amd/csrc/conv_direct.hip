@@ -1,0 +1,189 @@
+// Direct 3x3 stride-1 convolution for the narrow layers of the projection-domain UNet (4/8/16 channels at
+// 2000x912 and 1000x456, the stem, the eps output conv): Cout <= 16 and Cin <= 160 (the 144->16 up-block conv included: 71 TF/s on the VALU vs 46 on half-empty MFMA tiles).
+//
+// These layers carry 2 % of the FLOPs but took 21 % of a proj forward on the 32-cout MFMA tiles (4-16x padding
+// waste; profiles/r01c layer sweep).  Their arithmetic intensity (Cin*Cout*18 / ((Cin+Cout)*4) = 9-36 FLOP/B) is at
+// or below the HBM ridge, so the right bound is HBM and the right unit is the packed-f32 VALU:
+//   * workgroup = 256 threads = a 64 x 16 pixel tile; a thread owns 4 consecutive pixels of one row for ALL couts
+//     (4*CO accumulators), so an input value is read from LDS once per thread and used 9*CO/ (3 overlap) times;
+//   * the haloed input tile [8 ch][18][68] is staged through LDS with the same fused prologue as the MFMA kernels
+//     (nearest up-sampling + concat as addressing, GroupNorm(+SiLU), zero padding after the activation);
+//   * weights of the channel chunk sit in LDS as [ch][tap][CO] and are read as broadcast ds_read_b128 (all lanes
+//     the same address); the inner product is v_pk_fma_f32 over cout pairs with the input value broadcast;
+//   * epilogue: + bias (+ residual), 16-byte stores of the 4 pixels per cout.
+#include <cstdlib>
+#include "common.h"
+#include "unet_kernels.h"
+
+using namespace ipdm;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int DT_W = 64, DT_H = 16, DKC = 8;
+constexpr int DIN_H = DT_H + 2, DIN_W = DT_W + 2, DIN_P = 68;      // row pitch: 16-byte aligned runs of 4
+constexpr int DIN_CH = DIN_H * DIN_P;
+
+__device__ inline float silu_d(float v)
+{
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * v);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int CO>
+__global__ void __launch_bounds__(256) conv3x3_direct_kernel(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float in_lds[DKC * DIN_CH];
+    __shared__ __attribute__((aligned(16))) float w_lds[DKC * 9 * CO];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int n = blockIdx.z;
+    const int ox0 = blockIdx.x * DT_W, oy0 = blockIdx.y * DT_H;
+    const int Ctot = a.C1 + a.C2;
+    const int src_plane = a.Hs * a.Ws;
+
+    f32x2 acc[4][CO / 2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < CO / 2; ++c) acc[p][c] = f32x2{0.0f, 0.0f};
+
+    // staging descriptors: element e of the tile = (row r, col c) for every channel of a chunk
+    constexpr int NSP = (DIN_H * DIN_W + 255) / 256;
+    int sp_src[NSP], sp_dst[NSP];
+    bool sp_ok[NSP];
+#pragma unroll
+    for (int j = 0; j < NSP; ++j) {
+        const int e = tid + j * 256;
+        const int r = e / DIN_W, c = e % DIN_W;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
+        sp_ok[j] = e < DIN_H * DIN_W && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        int sy = min(max(iy, 0), a.H - 1), sx = min(max(ix, 0), a.W - 1);
+        if (a.upsample) {   // F.interpolate(mode="nearest"): src = min(floor(dst * (in/out) in f32), in-1)
+            sy = min((int)floorf((float)sy * a.scale_y), a.Hs - 1);
+            sx = min((int)floorf((float)sx * a.scale_x), a.Ws - 1);
+        }
+        sp_src[j] = sy * a.Ws + sx;
+        sp_dst[j] = e < DIN_H * DIN_W ? r * DIN_P + c : -1;
+    }
+
+    for (int c0 = 0; c0 < Ctot; c0 += DKC) {
+        const int kc = min(DKC, Ctot - c0);
+        __syncthreads();                                   // previous chunk fully consumed
+        // all global loads of the chunk first (one latency), then the transform
+        float raw[DKC][NSP];
+#pragma unroll
+        for (int c = 0; c < DKC; ++c) {
+            const int cg = min(c0 + c, Ctot - 1);          // channels beyond Cin re-read the last one; they are not consumed
+            const float *src = cg < a.C1 ? a.x1 + ((size_t)n * a.C1 + cg) * src_plane
+                                         : a.x2 + ((size_t)n * a.C2 + (cg - a.C1)) * src_plane;
+#pragma unroll
+            for (int j = 0; j < NSP; ++j) raw[c][j] = src[sp_src[j]];
+        }
+#pragma unroll
+        for (int c = 0; c < DKC; ++c) {
+            if (c < kc) {
+                float sc = 1.0f, sh = 0.0f;
+                if (a.act) { sc = a.gn_scale[(size_t)n * Ctot + c0 + c]; sh = a.gn_shift[(size_t)n * Ctot + c0 + c]; }
+#pragma unroll
+                for (int j = 0; j < NSP; ++j) {
+                    float v = raw[c][j];
+                    if (a.act) {
+                        v = v * sc + sh;
+                        if (a.act == 2) v = silu_d(v);
+                    }
+                    if (sp_dst[j] >= 0) in_lds[c * DIN_CH + sp_dst[j]] = sp_ok[j] ? v : 0.0f;
+                }
+            }
+        }
+        // weights: packed [Cin_pad8][9][cout_pad] (plain layout), cout_pad >= CO
+        for (int e = tid; e < kc * 9 * CO; e += 256) {
+            const int co = e % CO, rest = e / CO;          // rest = c*9 + tap
+            w_lds[e] = a.w[((size_t)c0 * 9 + rest) * a.cout_pad + co];
+        }
+        __syncthreads();
+        for (int c = 0; c < kc; ++c) {
+            const float *ip = in_lds + c * DIN_CH + ty * DIN_P + tx * 4;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(ip + ky * DIN_P);
+                const f32x2 hi = *reinterpret_cast<const f32x2 *>(ip + ky * DIN_P + 4);
+                const float iv[6] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1]};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float *wp = w_lds + (c * 9 + ky * 3 + kx) * CO;
+                    f32x2 wv[CO / 2];
+#pragma unroll
+                    for (int q = 0; q < CO / 4; ++q) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wp + q * 4);      // broadcast read
+                        wv[2 * q] = f32x2{w4[0], w4[1]};
+                        wv[2 * q + 1] = f32x2{w4[2], w4[3]};
+                    }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int q = 0; q < CO / 2; ++q) acc[p][q] += wv[q] * iv[p + kx];
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: + bias (+ residual); 4 consecutive pixels per cout
+    const int oy = oy0 + ty, ox = ox0 + tx * 4;
+    if (oy >= a.Ho || ox >= a.Wo) return;
+    const size_t out_plane = (size_t)a.Ho * a.Wo;
+    const bool vec = (a.Wo & 3) == 0;                      // ox is a multiple of 4: whole run inside, 16-byte aligned
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        if (co < a.Cout) {
+            const float b = a.bias ? a.bias[co] : 0.0f;
+            const size_t o = ((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wo + ox;
+            f32x4 v = {acc[0][co / 2][co & 1] + b, acc[1][co / 2][co & 1] + b, acc[2][co / 2][co & 1] + b, acc[3][co / 2][co & 1] + b};
+            if (vec) {
+                if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + o);
+                *reinterpret_cast<f32x4 *>(a.out + o) = v;
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (ox + p < a.Wo) a.out[o + p] = v[p] + (a.res ? a.res[o + p] : 0.0f);
+            }
+        }
+    }
+}
+
+template <int CO>
+int launch_direct(const ConvArgs &a, hipStream_t st)
+{
+    dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
+    const bool prof = prof_enabled();
+    if (prof) prof_before(1, st);
+    hipLaunchKernelGGL((conv3x3_direct_kernel<CO>), grid, dim3(256), 0, st, a);
+    if (prof) prof_after(1, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * 9, st);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+}  // namespace
+
+namespace ipdm {
+
+bool conv_direct_eligible(const ConvArgs &a)
+{
+    static const int max_cin = getenv("IPDM_DIRECT_MAX_CIN") ? atoi(getenv("IPDM_DIRECT_MAX_CIN")) : 160;
+    const int cin = a.C1 + a.C2;
+    return a.ksize == 3 && a.stride == 1 && a.Cout <= 16 && (cin <= max_cin || (a.Cout <= 4 && cin <= 128)) && a.w_interleave == 0 &&
+           a.cout_pad >= 16;
+}
+
+int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
+{
+    IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 31) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 31),
+                 "conv2d: per-sample tensor exceeds 32-bit offsets");
+    if (a.Cout <= 4) return launch_direct<4>(a, st);
+    if (a.Cout <= 8) return launch_direct<8>(a, st);
+    return launch_direct<16>(a, st);
+}
+
+}  // namespace ipdm

@@ -29,6 +29,8 @@ struct ConvArgs {
 
 int conv2d_launch(const ConvArgs &a, hipStream_t st);
 int conv2d_ws_launch(const ConvArgs &a, hipStream_t st);   // persistent wave-specialised variant (conv_ws.hip)
+bool conv_direct_eligible(const ConvArgs &a);             // narrow layers: direct packed-f32 VALU kernel (conv_direct.hip)
+int conv2d_direct_launch(const ConvArgs &a, hipStream_t st);
 int conv_k_chunk();   // concat inputs must split at a multiple of this many channels
 
 // per-launch HIP-event timing of kernel classes (bench.py roofline): 0 = conv 3x3 s1 wide tile (the
