@@ -15,19 +15,26 @@
 //     of the P.V MFMA, with V read from LDS as the A operand -- no data movement for P at all;
 //   * the output accumulator has the query on the lane too, so the online-softmax rescale is a
 //     per-lane multiply and the final store is coalesced along t.
-// K/V tiles of 64 keys x 64 channels are staged in LDS ([c][s] for K; [c][s] with an odd pitch
-// for V so that the 32 channel rows of one key hit 32 different banks).
+// Issue model (tools/ubench/coissue.hip): the f32 MFMA holds its wave's issue for its whole 64 cycles, so every
+// LDS read and VALU op of this kernel is ADDED to the MFMA time.  Hence
+//   * operands come in 16-byte LDS reads, 4 MFMAs per read: K is staged key-major [s][c] (the contraction runs over
+//     channels in the order c = 32*half + p, which makes a lane's 4 consecutive k-steps adjacent), V channel-major
+//     [c][s] (a lane's 4 consecutive P registers are 4 consecutive keys); pitch 68 keeps both conflict-free;
+//   * softmax is 4 VALU ops per score: max, fma, v_exp_f32 (base 2, log2(e) folded into the fma), add;
+//   * out-of-range keys are masked only in the ragged last block.
 #include "unet_kernels.h"
 
 using namespace ipdm;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int KV = 64;         // keys per LDS tile
-constexpr int KP = KV;         // K pitch  [c][s]
-constexpr int VP = KV + 1;     // V pitch  [c][s], odd -> conflict-free column reads
+constexpr int KP = 68;         // K pitch  [s][c]  (16-byte aligned rows, conflict-free b128 reads)
+constexpr int VP = 68;         // V pitch  [c][s]
+constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ inline int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -35,8 +42,8 @@ template <int D>   // head dim C/heads: 64 in both reference configs (256/4); 32
 __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restrict__ qkv, float *__restrict__ out,
                                                            int heads, int T, float scale)
 {
-    __shared__ float k_lds[D * KP];
-    __shared__ float v_lds[D * VP];
+    __shared__ __attribute__((aligned(16))) float k_lds[KV * KP];
+    __shared__ __attribute__((aligned(16))) float v_lds[D * VP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int bh = blockIdx.y;                      // sample*heads + head
@@ -47,11 +54,12 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
     const int t0 = blockIdx.x * 128 + wave * 32;
     const int t = t0 + l31;
     const bool tvalid = t < T;
+    constexpr int HP = D / 2;                       // k-steps; step p of half lh contracts channel lh*HP + p
 
-    // Q as the B operand of S = K^T Q: k-pair p covers channels (2p, 2p+1); lane holds q[2p+lh][t]*scale
-    float qreg[D / 2];
+    // Q as the B operand of S = K^T Q: lane holds q[lh*HP + p][t] * scale
+    float qreg[HP];
 #pragma unroll
-    for (int p = 0; p < D / 2; ++p) qreg[p] = tvalid ? qp[(size_t)(2 * p + lh) * T + t] * scale : 0.0f;
+    for (int p = 0; p < HP; ++p) qreg[p] = tvalid ? qp[(size_t)(lh * HP + p) * T + t] * scale : 0.0f;
 
     constexpr int CB = D / 32;
     f32x16 o[CB];
@@ -59,47 +67,53 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[cb][r] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;         // running max (natural-log domain scores), running sum
 
     for (int s0 = 0; s0 < T; s0 += KV) {
         __syncthreads();   // previous tile fully consumed
-        // stage K (scaled) and V: 64 channels x 64 keys each, coalesced along keys
+        // stage K (scaled, transposed to [s][c]) and V ([c][s]); global reads are coalesced along the keys
 #pragma unroll
         for (int e = 0; e < (D * KV) / 256; ++e) {
             const int idx = tid + e * 256;
             const int c = idx / KV, s = idx % KV;
             const bool ok = (s0 + s) < T;
-            k_lds[c * KP + s] = ok ? kp[(size_t)c * T + s0 + s] * scale : 0.0f;
+            k_lds[s * KP + c] = ok ? kp[(size_t)c * T + s0 + s] * scale : 0.0f;
             v_lds[c * VP + s] = ok ? vp[(size_t)c * T + s0 + s] : 0.0f;
         }
         __syncthreads();
 #pragma unroll
         for (int sb = 0; sb < KV / 32; ++sb) {
             if (s0 + sb * 32 >= T) break;          // wave-uniform
-            // ---- S[s, t] for 32 keys x 32 queries (K dim = 64 channels = 32 k-pairs)
+            // ---- S[s, t] for 32 keys x 32 queries
             f32x16 sacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+            const float *krow = k_lds + (sb * 32 + l31) * KP + lh * HP;
 #pragma unroll
-            for (int p = 0; p < D / 2; ++p) {
-                const float av = k_lds[(2 * p + lh) * KP + sb * 32 + l31];   // A[i=key][k=channel]
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qreg[p], sacc, 0, 0, 0);
+            for (int g = 0; g < HP / 4; ++g) {
+                const f32x4 kv = *reinterpret_cast<const f32x4 *>(krow + g * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[j], qreg[g * 4 + j], sacc, 0, 0, 0);
             }
             // ---- online softmax over keys (rows), per query (lane & 31)
-            float mx = -INFINITY;
+            if (s0 + sb * 32 + 32 > T) {            // ragged last block only (wave-uniform)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int s = s0 + sb * 32 + crow(r, lh);
-                if (s >= T) sacc[r] = -INFINITY;
-                mx = fmaxf(mx, sacc[r]);
+                for (int r = 0; r < 16; ++r)
+                    if (s0 + sb * 32 + crow(r, lh) >= T) sacc[r] = -INFINITY;
             }
+            float mx = sacc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = expf(m_run - m_new);          // m_run = -inf on the first block -> 0
+            const float mb = -m_new * LOG2E;
+            // exactly 1 while the running max stands (an fma against the rounded mb would leave a 1e-6 residual that
+            // compounds over the ~T/32 blocks); m_run = -inf on the first block -> 0
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
             float rs = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sacc[r] = expf(sacc[r] - m_new);
+                sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], LOG2E, mb));         // exp(s - m_new)
                 rs += sacc[r];
             }
             rs += __shfl_xor(rs, 32, 64);
@@ -110,14 +124,15 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
             // ---- O[c, t] += sum_s V[c, s] P[s, t]; accumulator register r of P is the k-pair
-            //      (s = crow(r,0) for lanes 0-31, crow(r,1) for lanes 32-63)
+            //      (s = crow(r,0) for lanes 0-31, crow(r,1) for lanes 32-63): registers 4g..4g+3 are 4 consecutive keys
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int s = sb * 32 + crow(r, lh);
+            for (int cb = 0; cb < CB; ++cb) {
+                const float *vrow = v_lds + (cb * 32 + l31) * VP + sb * 32 + 4 * lh;
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    const float av = v_lds[(cb * 32 + l31) * VP + s];      // A[i=channel][k=key]
-                    o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sacc[r], o[cb], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4 *>(vrow + 8 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j], sacc[4 * g + j], o[cb], 0, 0, 0);
                 }
             }
         }
