@@ -141,7 +141,7 @@ def main():
         _lib.call("ipdm_profile_end", C.byref(fl), C.byref(ms), C.byref(nl))
         if nl[0]:
             ach = fl[0] / (ms[0] * 1e-3) / 1e12
-            roofline = {"kernel": "conv_igemm_kernel<3,1,2,2> (3x3 s1 implicit GEMM, f32 MFMA)", "bound": "mfma",
+            roofline = {"kernel": "conv_ws_kernel<3,1,MB,NB,8> (3x3 stride-1 implicit GEMM, persistent wave-specialised, exact-f32 MFMA)", "bound": "mfma",
                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                         "launches": int(nl[0]), "avg_launch_ms": round(ms[0] / nl[0], 4),

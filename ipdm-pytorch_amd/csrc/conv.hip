@@ -359,11 +359,13 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
 }
 
 int conv_k_chunk() { return 8; }
+int conv_ws_k_chunk(int ks, int interleave) { return (interleave && ks == 1) ? 32 : 8; }
 
 int conv_weight_interleave(int Cout, int ks, int stride)
 {
     static const bool legacy = getenv("IPDM_CONV_LEGACY") != nullptr;
-    if (legacy || ks != 3 || stride != 1 || Cout <= 32) return 0;
+    static const bool legacy1 = getenv("IPDM_CONV1X1_LEGACY") != nullptr;
+    if (legacy || stride != 1 || Cout <= 32 || (ks != 3 && ks != 1) || (ks == 1 && legacy1)) return 0;
     return Cout > 96 ? 4 : 2;       // 128-cout tiles (MB=4,NB=2) for the wide layers, 64-cout x 16-row tiles (MB=2,NB=4) otherwise
 }
 
@@ -374,7 +376,8 @@ void conv_pack_weights(const float *w, int Cout, int Cin, int ks, int interleave
                        int &cout_pad)
 {
     const int group = interleave ? 32 * interleave : 64;
-    cin_pad = (Cin + 7) / 8 * 8;
+    const int kc = conv_ws_k_chunk(ks, interleave);           // channels per K chunk of the kernel that will read the slab
+    cin_pad = (Cin + kc - 1) / kc * kc;
     cout_pad = (Cout + group - 1) / group * group;
     const int taps = ks * ks;
     packed.assign((size_t)cin_pad * taps * cout_pad, 0.0f);

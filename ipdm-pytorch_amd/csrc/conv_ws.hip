@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
             w_voff[e] = v4 < T::W_TILE / 4 ? (row * a.cout_pad + col4 * 4) * 4 : OOB;
         }
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)a.w, 0, ((Ctot + 7) / 8 * 8) * T::TAPS * a.cout_pad * 4, 0x00020000);
+            (void *)a.w, 0, ((Ctot + KC - 1) / KC * KC) * T::TAPS * a.cout_pad * 4, 0x00020000);
         int in_voff[T::SP];
         bool in_ok[T::SP];
         TileId t = {0, 0, 0, 0};
@@ -453,7 +453,7 @@ int launch_ws(const ConvArgs &args, hipStream_t st, int prof_cls)
     IPDM_REQUIRE(a.C2 == 0 || a.C1 % KC == 0, "conv2d: concat split %d not a multiple of the K chunk %d", a.C1, KC);
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29) &&
                      (long)a.Cout * a.Ho * a.Wo < (1L << 29) &&
-                     (long)((a.C1 + a.C2 + 7) / 8 * 8) * T::TAPS * a.cout_pad < (1L << 29),
+                     (long)((a.C1 + a.C2 + KC - 1) / KC * KC) * T::TAPS * a.cout_pad < (1L << 29),
                  "conv2d: per-sample tensor exceeds the 2 GiB buffer-addressing range");
     const long ntiles = (long)a.tiles_x * a.tiles_y * a.co_tiles * a.B;
     IPDM_REQUIRE(ntiles < (1L << 31), "conv2d: too many tiles");
@@ -484,6 +484,9 @@ int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
 {
     if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 4) return launch_ws<3, 1, 4, 2, 8>(a, st, 0);
     if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 2) return launch_ws<3, 1, 2, 4, 8>(a, st, 0);
+    // 1x1: a plain GEMM over channels; 32-channel chunks give the producers 8k cycles of MFMA per hand-over
+    if (a.ksize == 1 && a.stride == 1 && a.w_interleave == 4) return launch_ws<1, 1, 4, 2, 32>(a, st, 1);
+    if (a.ksize == 1 && a.stride == 1 && a.w_interleave == 2) return launch_ws<1, 1, 2, 4, 32>(a, st, 1);
     set_error("conv2d_ws: unsupported ksize=%d stride=%d interleave=%d", a.ksize, a.stride, a.w_interleave);
     return IPDM_ERR_UNSUPPORTED;
 }

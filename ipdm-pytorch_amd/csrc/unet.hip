@@ -8,6 +8,7 @@
 //   GN statistics -> conv (GN+SiLU prologue, bias/residual epilogue) ..., flash attention.
 // Activations are NCHW fp32; the workspace is carved by a first-fit arena whose schedule is replayed
 // identically on every call (ipdm_unet_workspace_bytes runs the same walk without launching).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <map>
@@ -627,7 +628,14 @@ struct Fwd {
     {
         Tensor *h = nullptr;
         Tensor *cat = nullptr;
-        if (x2 && (x1->C % conv_k_chunk()) != 0) {
+        // the conv kernels walk K in chunks that must not straddle the two sources; the chunk depends on the kernels the
+        // block's first layer runs on (3x3: 8, wave-specialised 1x1 shortcut: 32)
+        int align = conv_k_chunk();
+        if (x2 && !layers.empty() && layers[0].kind == L_RES) {
+            const ResP &rp0 = net->res[layers[0].prefix];
+            if (rp0.has_sc) align = std::max(align, conv_ws_k_chunk(1, rp0.sc.interleave));
+        }
+        if (x2 && (x1->C % align) != 0) {
             // the conv kernel walks K in chunks that must not straddle the two sources: materialise torch.cat
             cat = make(x1->C + x2->C, x1->H, x1->W);
             if (!rc && !net->dry) {

@@ -31,7 +31,8 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st);
 int conv2d_ws_launch(const ConvArgs &a, hipStream_t st);   // persistent wave-specialised variant (conv_ws.hip)
 bool conv_direct_eligible(const ConvArgs &a);             // narrow layers: direct packed-f32 VALU kernel (conv_direct.hip)
 int conv2d_direct_launch(const ConvArgs &a, hipStream_t st);
-int conv_k_chunk();   // concat inputs must split at a multiple of this many channels
+int conv_k_chunk();   // concat inputs must split at a multiple of this many channels (3x3 kernels)
+int conv_ws_k_chunk(int ks, int interleave);   // K chunk of the kernel a (ks, weight layout) pair runs on: also its concat alignment
 
 // per-launch HIP-event timing of kernel classes (bench.py roofline): 0 = conv 3x3 s1 wide tile (the
 // dominant kernel), 1 = every other conv variant, 2 = attention

@@ -88,7 +88,7 @@ for name, cfg, (H, W) in (("img", UNetConfig(), (512, 512)),
     rows.sort(reverse=True)
     total = sum(r[0] for r in rows)
     print("== %s UNet forward, B=%d: %.1f ms in conv/attention launches, %.1f TFLOP/s overall" % (name, B, total, sum(r[3] * r[1] for r in rows) / total / 1e9))
-    for tt, n, t, fl, k in rows[:28]:
+    for tt, n, t, fl, k in (rows if os.environ.get("SWEEP_ALL") else rows[:28]):
         print("  %6.2f ms (%4.1f%%)  %2d x %7.3f ms  %6.1f TF/s  %s" % (tt, 100 * tt / total, n, t, fl / t / 1e9, k))
     for tt, n, t, fl, k in rows:
         if k[0] == "attn": f = "attention"
