@@ -38,7 +38,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ inline int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <int D>   // head dim C/heads: 64 in both reference configs (256/4); 32 for reduced test nets
+template <int D, int QT>   // D: head dim C/heads (64 in both reference configs, 32 for reduced test nets); QT: 32-query tiles per wave
 __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restrict__ qkv, float *__restrict__ out,
                                                            int heads, int T, float scale)
 {
@@ -51,23 +51,30 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
     const float *qp = qkv + ((size_t)b * heads * 3 * D + (size_t)head * 3 * D) * T;
     const float *kp = qp + (size_t)D * T;
     const float *vp = qp + (size_t)2 * D * T;
-    const int t0 = blockIdx.x * 128 + wave * 32;
-    const int t = t0 + l31;
-    const bool tvalid = t < T;
+    const int t0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
     constexpr int HP = D / 2;                       // k-steps; step p of half lh contracts channel lh*HP + p
 
-    // Q as the B operand of S = K^T Q: lane holds q[lh*HP + p][t] * scale
-    float qreg[HP];
+    // Q as the B operand of S = K^T Q: lane holds q[lh*HP + p][t] * scale, for QT query tiles (each LDS operand read
+    // then feeds QT MFMAs instead of one)
+    float qreg[QT][HP];
 #pragma unroll
-    for (int p = 0; p < HP; ++p) qreg[p] = tvalid ? qp[(size_t)(lh * HP + p) * T + t] * scale : 0.0f;
+    for (int qt = 0; qt < QT; ++qt) {
+        const int t = t0 + qt * 32 + l31;
+#pragma unroll
+        for (int p = 0; p < HP; ++p) qreg[qt][p] = t < T ? qp[(size_t)(lh * HP + p) * T + t] * scale : 0.0f;
+    }
 
     constexpr int CB = D / 32;
-    f32x16 o[CB];
+    f32x16 o[QT][CB];
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[cb][r] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;         // running max (natural-log domain scores), running sum
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qt][cb][r] = 0.0f;
+    float m_run[QT], l_run[QT];                     // running max (natural-log domain scores), running sum
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.0f; }
 
     for (int s0 = 0; s0 < T; s0 += KV) {
         __syncthreads();   // previous tile fully consumed
@@ -84,45 +91,54 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
 #pragma unroll
         for (int sb = 0; sb < KV / 32; ++sb) {
             if (s0 + sb * 32 >= T) break;          // wave-uniform
-            // ---- S[s, t] for 32 keys x 32 queries
-            f32x16 sacc;
+            // ---- S[s, t] for 32 keys x (QT x 32) queries
+            f32x16 sacc[QT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[qt][r] = 0.0f;
             const float *krow = k_lds + (sb * 32 + l31) * KP + lh * HP;
 #pragma unroll
             for (int g = 0; g < HP / 4; ++g) {
                 const f32x4 kv = *reinterpret_cast<const f32x4 *>(krow + g * 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[j], qreg[g * 4 + j], sacc, 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        sacc[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[j], qreg[qt][g * 4 + j], sacc[qt], 0, 0, 0);
             }
             // ---- online softmax over keys (rows), per query (lane & 31)
-            if (s0 + sb * 32 + 32 > T) {            // ragged last block only (wave-uniform)
+            const bool ragged = s0 + sb * 32 + 32 > T;     // last block only (wave-uniform)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (s0 + sb * 32 + crow(r, lh) >= T) sacc[r] = -INFINITY;
+            for (int qt = 0; qt < QT; ++qt) {
+                if (ragged) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (s0 + sb * 32 + crow(r, lh) >= T) sacc[qt][r] = -INFINITY;
+                }
+                float mx = sacc[qt][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[qt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[qt], mx);
+                const float mb = -m_new * LOG2E;
+                // exactly 1 while the running max stands (an fma against the rounded mb would leave a 1e-6 residual that
+                // compounds over the ~T/32 blocks); m_run = -inf on the first block -> 0
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * LOG2E);
+                float rs = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[qt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[qt][r], LOG2E, mb));     // exp(s - m_new)
+                    rs += sacc[qt][r];
+                }
+                rs += __shfl_xor(rs, 32, 64);
+                l_run[qt] = l_run[qt] * alpha + rs;
+                m_run[qt] = m_new;
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qt][cb][r] *= alpha;
             }
-            float mx = sacc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float mb = -m_new * LOG2E;
-            // exactly 1 while the running max stands (an fma against the rounded mb would leave a 1e-6 residual that
-            // compounds over the ~T/32 blocks); m_run = -inf on the first block -> 0
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-            float rs = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], LOG2E, mb));         // exp(s - m_new)
-                rs += sacc[r];
-            }
-            rs += __shfl_xor(rs, 32, 64);
-            l_run = l_run * alpha + rs;
-            m_run = m_new;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
             // ---- O[c, t] += sum_s V[c, s] P[s, t]; accumulator register r of P is the k-pair
             //      (s = crow(r,0) for lanes 0-31, crow(r,1) for lanes 32-63): registers 4g..4g+3 are 4 consecutive keys
 #pragma unroll
@@ -132,21 +148,28 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 vv = *reinterpret_cast<const f32x4 *>(vrow + 8 * g);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j], sacc[4 * g + j], o[cb], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt)
+                            o[qt][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j], sacc[qt][4 * g + j], o[qt][cb], 0, 0, 0);
                 }
             }
         }
     }
-    if (tvalid) {
-        const float inv = 1.0f / l_run;
-        float *op = out + ((size_t)b * heads * D + (size_t)head * D) * T;
+    float *op = out + ((size_t)b * heads * D + (size_t)head * D) * T;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
+    for (int qt = 0; qt < QT; ++qt) {
+        const int t = t0 + qt * 32 + l31;
+        if (t < T) {
+            const float inv = 1.0f / l_run[qt];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = cb * 32 + crow(r, lh);
-                op[(size_t)c * T + t] = o[cb][r] * inv;
-            }
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = cb * 32 + crow(r, lh);
+                    op[(size_t)c * T + t] = o[qt][cb][r] * inv;
+                }
+        }
     }
 }
 
@@ -160,11 +183,20 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
     if (d != 64 && d != 32) { set_error("attention: head dim %d unsupported (kernel is specialised for 64 and 32)", d); return IPDM_ERR_UNSUPPORTED; }
     // scale = 1/sqrt(sqrt(C/heads)) (Model/model.py:149); python double -> f32 scalar
     const float scale = (float)(1.0 / sqrt(sqrt((double)d)));
-    dim3 grid(cdiv(T, 128), B * heads);
+    // 64 queries per wave (K/V operand reads shared by two query tiles: 105 vs 93 TFLOP/s at T=4096) when the 256-query
+    // workgroups still fill the 512 resident slots evenly; a ragged second round (T=7125: 896 workgroups) costs more
+    // than the sharing gains, and small T keeps 32 queries per wave so that the chip stays filled
+    const long wg2 = (long)cdiv(T, 256) * B * heads;
+    const bool q2 = wg2 >= 512 && (wg2 % 512 == 0 || wg2 >= 4 * 512);
+    dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads);
     const bool prof = prof_enabled();
     if (prof) prof_before(2, st);
-    if (d == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, st, qkv, out, heads, T, scale);
-    else hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, st, qkv, out, heads, T, scale);
+    if (d == 64) {
+        if (q2) hipLaunchKernelGGL((attention_kernel<64, 2>), grid, dim3(256), 0, st, qkv, out, heads, T, scale);
+        else hipLaunchKernelGGL((attention_kernel<64, 1>), grid, dim3(256), 0, st, qkv, out, heads, T, scale);
+    } else {
+        hipLaunchKernelGGL((attention_kernel<32, 1>), grid, dim3(256), 0, st, qkv, out, heads, T, scale);
+    }
     if (prof) prof_after(2, 4.0 * B * heads * (double)T * T * d, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
