@@ -23,6 +23,19 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak (= f32 vector peak)
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
+    separate runs over one bench step, tools/profile_round.sh); counters cannot be collected inside a timed run, so the
+    newest committed summary under profiles/ is reported (null when there is none)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return int(d["traffic_bytes_per_launch"]), os.path.basename(files[-1])
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +156,8 @@ def main():
             ach = fl[0] / (ms[0] * 1e-3) / 1e12
             roofline = {"kernel": "conv_ws_kernel<3,1,MB,NB,8> (3x3 stride-1 implicit GEMM, persistent wave-specialised, exact-f32 MFMA)", "bound": "mfma",
                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic()[0],
+                        "traffic_source": measured_traffic()[1],
                         "launches": int(nl[0]), "avg_launch_ms": round(ms[0] / nl[0], 4),
                         "avg_launch_gflop": round(fl[0] / nl[0] / 1e9, 3)}
         for c, name in ((1, "conv_other"), (2, "attention")):

@@ -14,3 +14,6 @@ for shape in "8 128 0 512 512 128 3 1 2 1" "8 64 0 512 512 64 3 1 2 1"; do
   rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $OUT/${TAG}_pmc_grbm_$name -o c -- python3 tools/one_conv.py $shape > /dev/null 2>&1
 done
 find $OUT -name "*.csv" -path "*${TAG}*" | head -40
+# whole-step HBM traffic of every kernel (per-launch averages): two separate counter passes over one bench step
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pmc_step_fetch -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pmc_step_write -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>&1
