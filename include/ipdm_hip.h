@@ -81,6 +81,8 @@ int ipdm_schedule_destroy(ipdm_schedule *s);
  * sqrt_ac, sqrt_1m_ac, sqrt_recip_ac, sqrt_recipm1_ac, post_mean_coef1, post_mean_coef2,
  * post_log_var_clipped, post_var, each gathered at t and cast to float32. */
 int ipdm_schedule_coeffs(const ipdm_schedule *s, int32_t t, float out[8]);
+/* alphas_cumprod[t] gathered and cast to float32 (the _extract of ddim_sample, Model/model.py:683-684). */
+int ipdm_schedule_alpha_cumprod(const ipdm_schedule *s, int32_t t, float *out);
 /* cosine_beta_schedule(ts, schedule_power=power)[i] (Model/model.py:546,552), float64. */
 int ipdm_cosine_lambda(int32_t ts, double power, int32_t i, double *out);
 
@@ -102,6 +104,14 @@ int ipdm_ddpm_step(const ipdm_schedule *s, int32_t t, const float *d_eps_pred, c
                    const float *d_x0, const float *d_noise, float *d_out, int32_t B, int32_t H, int32_t W,
                    double lambda_scalar, const float *d_lambda_map, int32_t mh, int32_t mw,
                    int32_t clip_denoised, void *d_ws, size_t ws_bytes, void *stream);
+/* replaces one iteration of ddim_sample (Model/model.py:654-725; the sparse sampler of
+ * sparse_guided_reverse_process :727-759): guided, whitened eps as in ipdm_ddpm_step (scalar lambda), then the DDIM
+ * update from timestep t to t_prev.  d_cond is the guide image; d_noise may be NULL when ddim_eta == 0 (the reference
+ * still draws it -- the host mirror advances its noise source). */
+int ipdm_ddim_step(const ipdm_schedule *s, int32_t t, int32_t t_prev, const float *d_eps_pred, const float *d_x_t,
+                   const float *d_cond, const float *d_noise, float *d_out, int32_t B, int64_t n_per_slice,
+                   double lambda_scalar, double ddim_eta, int32_t clip_denoised, void *d_ws, size_t ws_bytes,
+                   void *stream);
 /* elementwise helpers of guided_reverse_process: out = clamp(x) (mode 0: [0,1], 1: min 0)
  * (Model/model.py:569-573); out = a*x + b*y + c*z (guide update :625-635; z may be NULL);
  * out = 0.5*(x+y) (:637-638). */

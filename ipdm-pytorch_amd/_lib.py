@@ -46,7 +46,9 @@ PROTOTYPES = {
     "ipdm_schedule_create": (C.c_int, [_i32, _f64, C.POINTER(_vp)]),
     "ipdm_schedule_destroy": (C.c_int, [_vp]),
     "ipdm_schedule_coeffs": (C.c_int, [_vp, _i32, C.POINTER(_f32 * 8)]),
+    "ipdm_schedule_alpha_cumprod": (C.c_int, [_vp, _i32, C.POINTER(_f32)]),
     "ipdm_cosine_lambda": (C.c_int, [_i32, _f64, _i32, C.POINTER(_f64)]),
+    "ipdm_ddim_step": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f64, _f64, _i32, _vp, _sz, _vp]),
     "ipdm_randn": (C.c_int, [_vp, _i32, _i64, _u64, _i64, _i64, _vp]),
     "ipdm_q_sample": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _vp]),
     "ipdm_ddpm_workspace_bytes": (_sz, [_i32]),

@@ -173,8 +173,14 @@ class progressive_domain_denoiser:
 
     def _proj_dense(self, x):
         o = self.opt
+        if o.sample_method_proj == "sparse":       # Utils/train_test_utils.py:445-453
+            res = self.proj_gaussian_diffusion.sparse_guided_reverse_process(
+                model=self.proj_model, condition=x.to(self.proj_device, torch.float32), t_start=o.t_start_proj,
+                condition_lambda_max=0.49, condition_lambda_min=0.35, clip_denoised=o.clip_proj,
+                ddim_timesteps=o.ddim_timesteps_proj, eta=o.eta_proj, noise=self._noise())
+            return res, None, self.noise_strength
         if o.sample_method_proj != "dense":
-            raise NotImplementedError("sample_method_proj='sparse' (DDIM) is a 'next' row (SURVEY.md 8f)")
+            raise ValueError("sample_method_proj must be 'dense' or 'sparse'")
         return self.proj_gaussian_diffusion.guided_reverse_process(
             model=self.proj_model, img=x.to(self.proj_device, torch.float32), t_start=o.t_start_proj, clip=o.clip_proj,
             lambda_ratio=o.lambda_ratio_proj, eta=o.eta_proj, mode="proj", constant_guidance=o.constant_guidance_proj,
@@ -183,15 +189,20 @@ class progressive_domain_denoiser:
 
     def _img_dense(self, x, noise_strength, ultra):
         o = self.opt
-        if o.sample_method_img != "dense":
-            raise NotImplementedError("sample_method_img='sparse' (DDIM) is a 'next' row (SURVEY.md 8f)")
+        if o.sample_method_img not in ("dense", "sparse"):
+            raise ValueError("sample_method_img must be 'dense' or 'sparse'")
         xd = x.to(self.img_device, torch.float32).contiguous()
         common = dict(model=self.img_model, clip=o.clip_img, lambda_ratio=o.lambda_ratio_img,
                       save_states=o.save_states_img, noise_strength=noise_strength, ldct=xd, mode="img",
                       kernel_size_img=o.kernel_size_img, amplitude_img=o.amplitude_img,
                       only_convertor=o.benchmark_test, normal=o.normal, noise=self._noise())
-        result, _, _ = self.img_gaussian_diffusion.guided_reverse_process(
-            img=xd, t_start=o.t_start_img, eta=o.eta_img, constant_guidance=o.constant_guidance_img, **common)
+        if o.sample_method_img == "sparse":        # Utils/train_test_utils.py:505-514
+            result = self.img_gaussian_diffusion.sparse_guided_reverse_process(
+                model=self.img_model, condition=xd, t_start=o.t_start_img, condition_lambda_max=0.5, condition_lambda_min=0.3,
+                clip_denoised=True, ddim_timesteps=o.ddim_timesteps_img, eta=o.eta_img, noise=self._noise())
+        else:
+            result, _, _ = self.img_gaussian_diffusion.guided_reverse_process(
+                img=xd, t_start=o.t_start_img, eta=o.eta_img, constant_guidance=o.constant_guidance_img, **common)
         if ultra:       # Utils/train_test_utils.py:515-536
             result_, _, _ = self.img_gaussian_diffusion.guided_reverse_process(
                 img=result[-1], t_start=[5, 5, 5], eta=0.6, constant_guidance=0.6, **common)

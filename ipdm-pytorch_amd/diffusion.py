@@ -231,6 +231,63 @@ class GaussianDiffusion:
             return iters_out[1:], reverse_states, noise_strength
         return iters_out, reverse_states, noise_strength
 
+    # ---- Model/model.py:654-725
+    @torch.no_grad()
+    def ddim_sample(self, sample_img, model, condition, t_start, condition_lambda=0.5, batch_size=1, ddim_timesteps=2,
+                    ddim_discr_method="uniform", ddim_eta=0.0, clip_denoised=True, noise=None):
+        """Same signature as the reference (+ `noise`).  One draw is consumed per step even when ddim_eta == 0,
+        as the reference's torch.randn_like call does (:716)."""
+        import numpy as np
+        if ddim_discr_method == "uniform":
+            seq = np.linspace(t_start - 1, 0, ddim_timesteps + 1).astype(int)[0:-1]
+        elif ddim_discr_method == "quad":
+            seq = ((np.linspace(0, np.sqrt(self.timesteps * .8), ddim_timesteps)) ** 2).astype(int)
+        else:
+            raise NotImplementedError('There is no ddim discretization method called "%s"' % ddim_discr_method)
+        prev_seq = np.append(seq[1:], np.array([0]))
+        noise = noise if noise is not None else NoiseSource(0)
+        x = sample_img.to(torch.float32).contiguous()
+        cond = condition.to(torch.float32).contiguous()
+        B = x.shape[0]
+        ws = self._workspace("step", lib().ipdm_ddpm_workspace_bytes(B), x.device)
+        for i in range(ddim_timesteps):
+            t, tp = int(seq[i]), int(prev_seq[i])
+            eps_pred = model(x, t)
+            z = noise.next_like(x)
+            out = torch.empty_like(x)
+            call("ipdm_ddim_step", self._h, t, tp, ptr(eps_pred), ptr(x), ptr(cond), ptr(z) if ddim_eta != 0 else None,
+                 ptr(out), B, x.numel() // B, float(condition_lambda), float(ddim_eta), 1 if clip_denoised else 0,
+                 ptr(ws), ws.numel(), _stream())
+            x = out
+        return x
+
+    # ---- Model/model.py:727-759
+    @torch.no_grad()
+    def sparse_guided_reverse_process(self, model, condition, t_start, condition_lambda_max=0.5, condition_lambda_min=0.25,
+                                      batch_size=1, ddim_timesteps=(2,), ddim_discr_method="uniform", ddim_eta=0.0,
+                                      eta=0.5, clip_denoised=True, noise=None):
+        """The sparse (DDIM) sampler: same signature and return value (list of per-pass results) as the reference."""
+        import numpy as np
+        noise = noise if noise is not None else NoiseSource(0)
+        condition = condition.to(torch.float32).contiguous()
+        sample_img = self.q_sample(condition, t_start[0], noise.next_like(condition))
+        condition_ = condition.clone()
+        n_it = len(t_start)
+        step = (condition_lambda_max - condition_lambda_min) / n_it
+        lam = np.arange(condition_lambda_max, condition_lambda_min - step, -step)
+        result = []
+        for i, t in enumerate(t_start):
+            sample_img = self.ddim_sample(sample_img=sample_img, model=model, condition=condition, t_start=t,
+                                          condition_lambda=lam[i], batch_size=batch_size, ddim_timesteps=ddim_timesteps[i],
+                                          ddim_discr_method=ddim_discr_method, ddim_eta=ddim_eta, clip_denoised=clip_denoised,
+                                          noise=noise)
+            nxt = torch.empty_like(sample_img)
+            call("ipdm_axpbypcz", ptr(sample_img), ptr(condition_), None, ptr(nxt), sample_img.numel(), float(eta), float(1 - eta),
+                 0.0, _stream())
+            condition = nxt
+            result.append(sample_img.clone())
+        return result
+
     def _guide_update(self, mode, eta, x, img, ldct):
         """Model/model.py:625-635."""
         out = torch.empty_like(x)

@@ -27,6 +27,16 @@ LOOP_CASES = {
                                                    constant_guidance=0.3)),
 }
 
+# sparse (DDIM) sampler: (shape, schedule power, kwargs of sparse_guided_reverse_process)
+SPARSE_CASES = {
+    "img": ((1, 1, 32, 32), 1, dict(t_start=[4, 3, 3], ddim_timesteps=[1, 2, 2], condition_lambda_max=0.5,
+                                    condition_lambda_min=0.3, eta=0.7, clip_denoised=True, ddim_eta=0.0)),
+    "proj": ((1, 1, 40, 24), 5, dict(t_start=[5, 4], ddim_timesteps=[2, 2], condition_lambda_max=0.49,
+                                     condition_lambda_min=0.35, eta=0.5, clip_denoised=False, ddim_eta=0.0)),
+    "img_eta": ((1, 1, 32, 32), 1, dict(t_start=[6, 4], ddim_timesteps=[3, 2], condition_lambda_max=0.5,
+                                        condition_lambda_min=0.3, eta=0.6, clip_denoised=True, ddim_eta=0.3)),
+}
+
 
 class noise_feed:
     """Hashed N(0,1) draws in call order: draw k of feed `seed` = hash_normal(shape, seed*1000+k)."""

@@ -63,7 +63,7 @@ def ref_unet(cfg, seed):
     return net, list(shapes.keys())
 
 
-from tests.golden.cases import SMALL_CFGS, SMALL_SHAPES, LOOP_CFG, LOOP_CASES  # noqa: E402
+from tests.golden.cases import SMALL_CFGS, SMALL_SHAPES, LOOP_CFG, LOOP_CASES, SPARSE_CASES  # noqa: E402
 
 
 def gen_unet():
@@ -181,6 +181,25 @@ def gen_loops():
     save("loops", **out)
 
 
+# ------------------------------------------------------------------ 6b. sparse_guided_reverse_process (DDIM)
+def gen_sparse():
+    out = {}
+    net, _ = ref_unet(LOOP_CFG, seed=41)
+    orig = torch.randn_like
+    try:
+        for tag, (shape, power, kw) in SPARSE_CASES.items():
+            gd = M.GaussianDiffusion(timesteps=1000, beta_schedule="cosine", schedule_power=power)
+            cond = torch.from_numpy(synth.hash_uniform(shape, 46)) * 0.6
+            feed = _NoiseFeed(47)
+            torch.randn_like = feed
+            res = gd.sparse_guided_reverse_process(model=net, condition=cond, **kw)
+            out[tag] = np.stack([r.numpy() for r in res])
+            out[tag + "_ndraws"] = np.array(feed.k)
+    finally:
+        torch.randn_like = orig
+    save("sparse", **out)
+
+
 # ------------------------------------------------------------------ 7. FBP
 def fbp_cpu_vectorised(fbp, pj):
     """fbp_cpu (Recon/FBP_kernel.py:166-184) with the pixel loops vectorised in numpy: identical
@@ -278,5 +297,6 @@ if __name__ == "__main__":
     gen_ops()
     gen_step()
     gen_loops()
+    gen_sparse()
     gen_misc()
     gen_fbp()

@@ -400,6 +400,33 @@ def test_guided_reverse_process_golden(golden):
         np.testing.assert_allclose(got, g[tag], rtol=0, atol=5e-5)
 
 
+def test_sparse_guided_reverse_process_golden(golden):
+    """sample_method='sparse' (DDIM, Model/model.py:654-759) through the C ABI against the reference's outputs."""
+    from ipdm_pytorch_amd.diffusion import GaussianDiffusion, InjectedNoise, NoiseSource
+    from tests.golden.cases import SPARSE_CASES
+    g = golden("sparse")
+    net, _ = _native_unet(LOOP_CFG, 41)
+    for tag, (shape, power, kw) in SPARSE_CASES.items():
+        gd = GaussianDiffusion(1000, "cosine", power)
+        cond = torch.from_numpy(synth.hash_uniform(shape, 46)) * 0.6
+        nd = int(g[tag + "_ndraws"])
+        noise = InjectedNoise([torch.from_numpy(synth.hash_normal(shape, 47 * 1000 + k)) for k in range(nd)])
+        res = gd.sparse_guided_reverse_process(model=net, condition=cond.to(DEV), noise=noise, **kw)
+        assert noise.draw == nd                                  # one draw per q_sample and per DDIM step, as torch.randn_like
+        got = np.stack([r.cpu().numpy() for r in res])
+        assert got.shape == g[tag].shape
+        np.testing.assert_allclose(got, g[tag], rtol=0, atol=5e-5)
+    # batch of two slices == two single-slice runs (per-slice statistics)
+    shape, power, kw = SPARSE_CASES["img"]
+    gd = GaussianDiffusion(1000, "cosine", power)
+    cond2 = torch.from_numpy(synth.hash_uniform((2,) + shape[1:], 48)) * 0.6
+    full = gd.sparse_guided_reverse_process(model=net, condition=cond2.to(DEV), noise=NoiseSource(5, 0), **kw)
+    for b in range(2):
+        one = gd.sparse_guided_reverse_process(model=net, condition=cond2[b:b + 1].to(DEV), noise=NoiseSource(5, b), **kw)
+        for k in range(len(full)):
+            assert torch.equal(full[k][b:b + 1], one[k])
+
+
 def test_guided_reverse_process_batch_equals_per_slice():
     """Per-slice semantics + shard invariance: B=3 in one call == three B=1 calls (bit-identical)."""
     from ipdm_pytorch_amd.diffusion import GaussianDiffusion, NoiseSource
@@ -453,3 +480,28 @@ def test_drop_in_surface():
     den.data_sample_load(ldproj=x)
     out, ns = den.proj_denoiser(den.ldproj, save_state=False)      # only_convertor short-circuit: FBP of the input
     assert isinstance(out, torch.Tensor) and out.device.type == "cpu" and tuple(out.shape) == (1, 1, 512, 512) and ns is None
+
+
+def test_drop_in_sparse_sample_method():
+    """update_opt(sample_method_*='sparse') routes both domains through the DDIM sampler with the reference's
+    hard-wired guidance ranges (Utils/train_test_utils.py:445-453,505-514) and keeps the result-dict conventions."""
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG
+    from ipdm_pytorch_amd.unet import UNetModel
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    den = progressive_domain_denoiser(opt, seed=3)
+    den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
+    den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
+    for m, seed in ((den.proj_model, 21), (den.img_model, 22)):
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(m._shapes, seed=seed).items()})
+    den.update_opt(dict(sample_method_proj="sparse", sample_method_img="sparse", t_start_proj=[4, 3], ddim_timesteps_proj=[2, 1],
+                        t_start_img=[3, 3], ddim_timesteps_img=[1, 2], ultra_img_denoise=False))
+    sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(2)), seed=2)
+    den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
+    out = den.progressive_denoiser(sharpen_num=70)
+    assert tuple(out.shape) == (1, 1, 512, 512) and bool(torch.isfinite(out).all())
+    assert len(den.progressive_denoise_result) == 1 and den.noise_strength is None
+    den.update_opt(dict(sample_method_img="nonsense"))
+    with pytest.raises(ValueError):
+        den.img_denoiser(out)

@@ -8,7 +8,7 @@ from oracle import fbp as of
 from oracle import unet as ou
 from ipdm_pytorch_amd import synth
 
-from tests.golden.cases import SMALL_CFGS, SMALL_SHAPES, LOOP_CFG, LOOP_CASES, noise_feed
+from tests.golden.cases import SPARSE_CASES, SMALL_CFGS, SMALL_SHAPES, LOOP_CFG, LOOP_CASES, noise_feed
 
 
 def test_schedule_tables(golden):
@@ -97,6 +97,20 @@ def test_guided_reverse_process(golden):
         assert feed.count == int(g[tag + "_ndraws"])       # same number of randn draws as the reference
         got = np.stack([r.numpy() for r in res])
         np.testing.assert_allclose(got, g[tag], rtol=0, atol=5e-6)
+
+
+def test_sparse_guided_reverse_process(golden):
+    """The sparse (DDIM) sampler (Model/model.py:654-759) against the reference's own outputs, incl. the draw count."""
+    g = golden("sparse")
+    cfg = ou.UNetConfig(**LOOP_CFG)
+    sd, _ = _sd(cfg, 41)
+    for tag, (shape, power, kw) in SPARSE_CASES.items():
+        sch = od.Schedule(1000, power)
+        cond = torch.from_numpy(synth.hash_uniform(shape, 46)) * 0.6
+        feed = noise_feed(47, shape)
+        res = od.sparse_guided_reverse_process_slice(sch, lambda x, t: ou.unet_forward(cfg, sd, x, t), cond, noise_fn=feed, **kw)
+        assert feed.count == int(g[tag + "_ndraws"])
+        np.testing.assert_allclose(np.stack([r.numpy() for r in res]), g[tag], rtol=0, atol=5e-6)
 
 
 def test_curves_sharpen_units(golden):
