@@ -40,7 +40,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-template <int KS, int STRIDE, int MB, int NB, int KC_>
+template <int KS, int STRIDE, int MB, int NB, int KC_, int IL = MB>   // IL: cout interleave of the packed weights (>= MB)
 struct WsTile {
     static constexpr int KC = KC_;
     static constexpr int TAPS = KS * KS;
@@ -52,8 +52,9 @@ struct WsTile {
     static constexpr int SP = (IN_CH + 255) / 256;           // staging slots per producer thread per channel
     static constexpr int IN_CHP = SP * 256;                  // LDS channel pitch: every (thread, slot) owns an address
     static constexpr int IN_TILE = KC * IN_CHP;
-    static constexpr int BN = 32 * MB;
-    static constexpr int W_TILE = KC * TAPS * BN;
+    static constexpr int BN = 32 * MB;                       // couts per tile
+    static constexpr int LW = 32 * IL;                       // couts per weight-slab row (one interleave group)
+    static constexpr int W_TILE = KC * TAPS * LW;
     static constexpr int W_VEC = (W_TILE / 4 + 255) / 256;   // 16-byte weight loads per producer thread per chunk
     static constexpr int W_TILEP = W_VEC * 256 * 4;
     static constexpr int BUF = IN_TILE + W_TILEP;
@@ -101,10 +102,10 @@ __device__ inline f32x2 gn_silu2(f32x2 x, float sc, float sh)
     return z * e;
 }
 
-template <int KS, int STRIDE, int MB, int NB, int KC>
+template <int KS, int STRIDE, int MB, int NB, int KC, int IL>
 __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
 {
-    using T = WsTile<KS, STRIDE, MB, NB, KC>;
+    using T = WsTile<KS, STRIDE, MB, NB, KC, IL>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     // ---- static tile schedule: at step k the G workgroups cover tiles [kG,(k+1)G); the workgroups of one XCD
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
 #pragma unroll
         for (int e = 0; e < T::W_VEC; ++e) {
             const int v4 = tid + e * 256;
-            const int row = v4 / (T::BN / 4), col4 = v4 % (T::BN / 4);
+            const int row = v4 / (T::LW / 4), col4 = v4 % (T::LW / 4);
             w_voff[e] = v4 < T::W_TILE / 4 ? (row * a.cout_pad + col4 * 4) * 4 : OOB;
         }
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 const int cs0 = from1 ? c0 : c0 - a.C1;
                 // weights first (they need no transform and go to LDS as soon as they land), then the raw input tile
                 f32x4 w_reg[T::W_VEC];
-                const int w_soff = (c0 * T::TAPS * a.cout_pad + t.co0) * 4;
+                const int w_soff = (c0 * T::TAPS * a.cout_pad + t.co0 / T::LW * T::LW) * 4;   // the whole interleave group of the tile
 #pragma unroll
                 for (int e = 0; e < T::W_VEC; ++e)
                     w_reg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[e], w_soff, 0));
@@ -265,6 +266,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     constexpr int NP = KC / 2;
 
     f32x16 acc[MB][NB];
+    int sub = 0;
     unsigned long long t_mma = 0, t_epi = 0, t_bar = 0, t_last = 0;
     const bool stamp = (a.dbg & 8) != 0;
     const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
@@ -299,6 +301,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
         }
         const float *ib = lds + (s & 1) * T::BUF;
         const float *wb = ib + T::IN_TILE;
+        if (IL != MB && ch == 0) sub = decode_tile<T::TH, T::TW, T::BN>(a, tile_of(k)).co0 % T::LW / 32;   // m offset inside the group
         {
             // operands: B = the ROWS x KS input values of one channel pair this wave touches (fetched one pair
             // ahead), A = the MB weight values of one tap (fetched one tap ahead); channels beyond Cin are zero
@@ -315,7 +318,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
             auto read_a = [&](int cp, int t, float (&A)[MB]) __attribute__((always_inline)) {
                 const int c = cp * 2 + lk;
                 typedef float fvec __attribute__((ext_vector_type(MB)));
-                const fvec v = *reinterpret_cast<const fvec *>(wb + ((c * T::TAPS + t) * 32 + l31) * MB);   // [c][tap][l31][m]
+                const fvec v = *reinterpret_cast<const fvec *>(wb + ((c * T::TAPS + t) * 32 + l31) * IL + sub);   // [c][tap][l31][m]
 #pragma unroll
                 for (int m = 0; m < MB; ++m) A[m] = v[m];
             };
@@ -439,10 +442,10 @@ int num_cus()
     return n;
 }
 
-template <int KS, int STRIDE, int MB, int NB, int KC>
+template <int KS, int STRIDE, int MB, int NB, int KC, int IL = MB>
 int launch_ws(const ConvArgs &args, hipStream_t st, int prof_cls)
 {
-    using T = WsTile<KS, STRIDE, MB, NB, KC>;
+    using T = WsTile<KS, STRIDE, MB, NB, KC, IL>;
     static_assert(T::LDS_BYTES <= 160 * 1024, "conv_ws: LDS stages exceed 160 KiB");
     ConvArgs a = args;
     static const int dbg = getenv("IPDM_CONV_DBG") ? atoi(getenv("IPDM_CONV_DBG")) : 0;
@@ -462,13 +465,13 @@ int launch_ws(const ConvArgs &args, hipStream_t st, int prof_cls)
     G = (G + 7) / 8 * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC>,
+        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
         attr_set = true;
     }
     const bool prof = prof_enabled();
     if (prof) prof_before(prof_cls, st);
-    hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC>), dim3((unsigned)G), dim3(512), T::LDS_BYTES, st, a, (int)ntiles);
+    hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL>), dim3((unsigned)G), dim3(512), T::LDS_BYTES, st, a, (int)ntiles);
     if (prof) prof_after(prof_cls, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
@@ -482,7 +485,13 @@ namespace ipdm {
 // conv_weight_interleave / conv_pack_weights).
 int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
 {
-    if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 4) return launch_ws<3, 1, 4, 2, 8>(a, st, 0);
+    if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 4) {
+        // layers whose 8x32x128 tiling gives fewer tiles than CUs (32x32 and 63x29 at 256 channels) use 4x32x64 tiles
+        // over the same packed weights: 4x the workgroups, each reading its half of the 128-cout interleave group
+        const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128) * a.B;
+        if (tiles < 160) return launch_ws<3, 1, 2, 1, 8, 4>(a, st, 0);
+        return launch_ws<3, 1, 4, 2, 8>(a, st, 0);
+    }
     if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 2) return launch_ws<3, 1, 2, 4, 8>(a, st, 0);
     // 1x1: a plain GEMM over channels; 32-channel chunks give the producers 8k cycles of MFMA per hand-over
     if (a.ksize == 1 && a.stride == 1 && a.w_interleave == 4) return launch_ws<1, 1, 4, 2, 32>(a, st, 1);
