@@ -111,8 +111,10 @@ def main():
     rank, world, local = idist.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    device = "cuda:%d" % local
-    torch.cuda.set_device(local)
+    # one rank per GPU; IPDM_BENCH_SHARE_GPU=1 (plumbing test on a 1-GPU box) puts every rank on device 0
+    dev_index = 0 if os.environ.get("IPDM_BENCH_SHARE_GPU") else local
+    device = "cuda:%d" % dev_index
+    torch.cuda.set_device(dev_index)
 
     opt = default_cfg([])
     cfg_load(mayo_test_options(), opt.__dict__)

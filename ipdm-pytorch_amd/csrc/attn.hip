@@ -134,10 +134,13 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
                 rs += __shfl_xor(rs, 32, 64);
                 l_run[qt] = l_run[qt] * alpha + rs;
                 m_run[qt] = m_new;
+                // the running max settles after the first few key blocks: skip the 32 multiplies by exactly 1.0 (wave-uniform)
+                if (__any(alpha != 1.0f)) {
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb)
+                    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[qt][cb][r] *= alpha;
+                        for (int r = 0; r < 16; ++r) o[qt][cb][r] *= alpha;
+                }
             }
             // ---- O[c, t] += sum_s V[c, s] P[s, t]; accumulator register r of P is the k-pair
             //      (s = crow(r,0) for lanes 0-31, crow(r,1) for lanes 32-63): registers 4g..4g+3 are 4 consecutive keys
