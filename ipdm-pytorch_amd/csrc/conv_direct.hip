@@ -1,4 +1,4 @@
-// Direct 3x3 stride-1 convolution for the narrow layers of the projection-domain UNet (4/8/16 channels at
+// Direct 3x3 / 1x1 stride-1 convolution for the narrow layers of the projection-domain UNet (4/8/16 channels at
 // 2000x912 and 1000x456, the stem, the eps output conv): Cout <= 16 and Cin <= 160 (the 144->16 up-block conv included: 71 TF/s on the VALU vs 46 on half-empty MFMA tiles).
 //
 // These layers carry 2 % of the FLOPs but took 21 % of a proj forward on the 32-cout MFMA tiles (4-16x padding
@@ -23,8 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int DT_W = 64, DT_H = 16, DKC = 8;
-constexpr int DIN_H = DT_H + 2, DIN_W = DT_W + 2, DIN_P = 68;      // row pitch: 16-byte aligned runs of 4
-constexpr int DIN_CH = DIN_H * DIN_P;
+constexpr int DIN_P = 68;      // LDS row pitch: 16-byte aligned runs of 4 (+ halo)
 
 __device__ inline float silu_d(float v)
 {
@@ -32,11 +31,12 @@ __device__ inline float silu_d(float v)
     return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-template <int CO>
-__global__ void __launch_bounds__(256) conv3x3_direct_kernel(ConvArgs a)
+template <int CO, int KS>
+__global__ void __launch_bounds__(256) conv_direct_kernel(ConvArgs a)
 {
+    constexpr int DIN_H = DT_H + KS - 1, DIN_W = DT_W + KS - 1, DIN_CH = DIN_H * DIN_P, TAPS = KS * KS, PAD = KS / 2;
     __shared__ __attribute__((aligned(16))) float in_lds[DKC * DIN_CH];
-    __shared__ __attribute__((aligned(16))) float w_lds[DKC * 9 * CO];
+    __shared__ __attribute__((aligned(16))) float w_lds[DKC * TAPS * CO];
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const int n = blockIdx.z;
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) conv3x3_direct_kernel(ConvArgs a)
     for (int j = 0; j < NSP; ++j) {
         const int e = tid + j * 256;
         const int r = e / DIN_W, c = e % DIN_W;
-        const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
+        const int iy = oy0 - PAD + r, ix = ox0 - PAD + c;
         sp_ok[j] = e < DIN_H * DIN_W && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         int sy = min(max(iy, 0), a.H - 1), sx = min(max(ix, 0), a.W - 1);
         if (a.upsample) {   // F.interpolate(mode="nearest"): src = min(floor(dst * (in/out) in f32), in-1)
@@ -99,21 +99,22 @@ __global__ void __launch_bounds__(256) conv3x3_direct_kernel(ConvArgs a)
             }
         }
         // weights: packed [Cin_pad8][9][cout_pad] (plain layout), cout_pad >= CO
-        for (int e = tid; e < kc * 9 * CO; e += 256) {
-            const int co = e % CO, rest = e / CO;          // rest = c*9 + tap
-            w_lds[e] = a.w[((size_t)c0 * 9 + rest) * a.cout_pad + co];
+        for (int e = tid; e < kc * TAPS * CO; e += 256) {
+            const int co = e % CO, rest = e / CO;          // rest = c*TAPS + tap
+            w_lds[e] = a.w[((size_t)c0 * TAPS + rest) * a.cout_pad + co];
         }
         __syncthreads();
         for (int c = 0; c < kc; ++c) {
             const float *ip = in_lds + c * DIN_CH + ty * DIN_P + tx * 4;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int ky = 0; ky < KS; ++ky) {
                 const f32x4 lo = *reinterpret_cast<const f32x4 *>(ip + ky * DIN_P);
-                const f32x2 hi = *reinterpret_cast<const f32x2 *>(ip + ky * DIN_P + 4);
+                f32x2 hi = {0.0f, 0.0f};
+                if (KS > 1) hi = *reinterpret_cast<const f32x2 *>(ip + ky * DIN_P + 4);
                 const float iv[6] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1]};
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float *wp = w_lds + (c * 9 + ky * 3 + kx) * CO;
+                for (int kx = 0; kx < KS; ++kx) {
+                    const float *wp = w_lds + (c * TAPS + ky * KS + kx) * CO;
                     f32x2 wv[CO / 2];
 #pragma unroll
                     for (int q = 0; q < CO / 4; ++q) {
@@ -153,14 +154,14 @@ __global__ void __launch_bounds__(256) conv3x3_direct_kernel(ConvArgs a)
     }
 }
 
-template <int CO>
+template <int CO, int KS>
 int launch_direct(const ConvArgs &a, hipStream_t st)
 {
     dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
     const bool prof = prof_enabled();
     if (prof) prof_before(1, st);
-    hipLaunchKernelGGL((conv3x3_direct_kernel<CO>), grid, dim3(256), 0, st, a);
-    if (prof) prof_after(1, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * 9, st);
+    hipLaunchKernelGGL((conv_direct_kernel<CO, KS>), grid, dim3(256), 0, st, a);
+    if (prof) prof_after(1, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }
@@ -173,7 +174,7 @@ bool conv_direct_eligible(const ConvArgs &a)
 {
     static const int max_cin = getenv("IPDM_DIRECT_MAX_CIN") ? atoi(getenv("IPDM_DIRECT_MAX_CIN")) : 160;
     const int cin = a.C1 + a.C2;
-    return a.ksize == 3 && a.stride == 1 && a.Cout <= 16 && (cin <= max_cin || (a.Cout <= 4 && cin <= 128)) && a.w_interleave == 0 &&
+    return (a.ksize == 3 || a.ksize == 1) && a.stride == 1 && a.Cout <= 16 && (cin <= max_cin || (a.Cout <= 4 && cin <= 128)) && a.w_interleave == 0 &&
            a.cout_pad >= 16;
 }
 
@@ -181,9 +182,14 @@ int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
 {
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 31) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 31),
                  "conv2d: per-sample tensor exceeds 32-bit offsets");
-    if (a.Cout <= 4) return launch_direct<4>(a, st);
-    if (a.Cout <= 8) return launch_direct<8>(a, st);
-    return launch_direct<16>(a, st);
+    if (a.ksize == 1) {     // the 1x1 shortcuts of the narrow levels: pure streaming
+        if (a.Cout <= 4) return launch_direct<4, 1>(a, st);
+        if (a.Cout <= 8) return launch_direct<8, 1>(a, st);
+        return launch_direct<16, 1>(a, st);
+    }
+    if (a.Cout <= 4) return launch_direct<4, 3>(a, st);
+    if (a.Cout <= 8) return launch_direct<8, 3>(a, st);
+    return launch_direct<16, 3>(a, st);
 }
 
 }  // namespace ipdm

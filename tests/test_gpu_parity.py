@@ -296,6 +296,11 @@ def _conv_case(B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res, seed):
     (2, 192, 0, 10, 12, 10, 12, 128, 1, 1, 0, True),        # shortcut 1x1 + residual
     (1, 64, 0, 70, 100, 70, 100, 1, 3, 1, 2, False),        # out conv, Cout=1
     (1, 130, 0, 12, 33, 12, 33, 70, 3, 1, 0, False),        # channels not multiples of the tile sizes
+    (1, 8, 4, 33, 57, 33, 57, 8, 1, 1, 0, False),           # narrow 1x1 shortcut over a concat (direct kernel)
+    (2, 16, 0, 20, 70, 20, 70, 16, 1, 1, 0, True),          # narrow 1x1 + residual, width not a multiple of 4
+    (1, 144, 0, 24, 40, 24, 40, 16, 3, 1, 2, False),        # 144 -> 16 up-block conv (direct kernel, 18 channel chunks)
+    (8, 128, 0, 64, 96, 64, 96, 128, 3, 1, 2, True),        # enough tiles for the 8x32x128 persistent schedule (several rounds)
+    (2, 64, 64, 48, 40, 48, 40, 64, 3, 1, 2, True),         # 16x32x64 tiles, concat, ragged right edge
 ])
 def test_conv_kernel(case):
     _conv_case(*case, seed=200 + sum(case[:8]))
