@@ -417,7 +417,54 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                         }
                     }
             };
-            if (t.co0 + T::BN <= a.Cout) epilogue(std::false_type{});
+            // Fast path (rows are a multiple of 4 pixels long, full cout tile): 16 bytes per lane and store.  The
+            // accumulator holds, per lane (= pixel) and register group g, 4 consecutive COUTS; a 4x4 transpose inside
+            // every quad of lanes (DPP quad_perm + select, 8-16 VALU per block) turns that into 4 consecutive PIXELS of one
+            // cout per lane, so one buffer_store_dwordx4 replaces four dword stores (the store path retires ~1 instruction
+            // per 100 cycles per wave regardless of its width) and a half-wave still writes 4 full 128-byte row segments.
+            if ((a.Wo & 3) == 0 && t.co0 + T::BN <= a.Cout && !(a.dbg & 64)) {
+                const int qi = l31 & 3, qp = l31 >> 2;
+                const int lane_off4 = ((qi + 4 * lk) * out_plane + 4 * qp) * 4;
+                const bool xok = t.ox0 + 4 * qp + 4 <= a.Wo;
+                int voff4[NB];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) voff4[q] = (xok && t.oy0 + swave * NB + q < a.Ho) ? lane_off4 : OOB;
+                const bool odd = (l31 & 1) != 0, hi = (l31 & 2) != 0;
+#define IPDM_XCHG(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
+                auto block = [&](int m, int q, int g) __attribute__((always_inline)) -> f32x4 {
+                    float r0 = acc[m][q][4 * g], r1 = acc[m][q][4 * g + 1], r2 = acc[m][q][4 * g + 2], r3 = acc[m][q][4 * g + 3];
+                    // lanes i^1 exchange registers j^1 (quad_perm [1,0,3,2]), then lanes i^2 exchange registers j^2 ([2,3,0,1])
+                    float x = IPDM_XCHG(r0, 0xB1), y = IPDM_XCHG(r1, 0xB1);
+                    r0 = odd ? y : r0; r1 = odd ? r1 : x;
+                    x = IPDM_XCHG(r2, 0xB1); y = IPDM_XCHG(r3, 0xB1);
+                    r2 = odd ? y : r2; r3 = odd ? r3 : x;
+                    x = IPDM_XCHG(r0, 0x4E); y = IPDM_XCHG(r2, 0x4E);
+                    r0 = hi ? y : r0; r2 = hi ? r2 : x;
+                    x = IPDM_XCHG(r1, 0x4E); y = IPDM_XCHG(r3, 0x4E);
+                    r1 = hi ? y : r1; r3 = hi ? r3 : x;
+                    return f32x4{r0, r1, r2, r3};
+                };
+#undef IPDM_XCHG
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        const int so = (t.co0 + m * 32) * plane4 + rowq[q];
+                        f32x4 rv[4];
+                        if (a.res) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                rv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4[q], so + 8 * g * plane4, 0));
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v = block(m, q, g);
+                            if (a.res) v += rv[g];
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4[q], so + 8 * g * plane4, 0);
+                        }
+                    }
+            } else if (t.co0 + T::BN <= a.Cout) epilogue(std::false_type{});
             else epilogue(std::true_type{});
         }
         if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_epi += now - t_last; t_last = now; }
