@@ -22,6 +22,7 @@
 //     [c][s] (a lane's 4 consecutive P registers are 4 consecutive keys); pitch 68 keeps both conflict-free;
 //   * softmax is 4 VALU ops per score: max, fma, v_exp_f32 (base 2, log2(e) folded into the fma), add;
 //   * out-of-range keys are masked only in the ragged last block.
+#include <cstdlib>
 #include "unet_kernels.h"
 
 using namespace ipdm;
@@ -176,6 +177,161 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
     }
 }
 
+// Wave-specialised variant (same arithmetic, same instruction order per query): waves 0-3 are consumers (Q in
+// registers, MFMAs, softmax), waves 4-7 stage the NEXT K/V tile into the other LDS stage while the consumers work on the
+// current one -- global loads, LDS stores and the barrier latency leave the MFMA waves; one hand-over barrier per tile.
+// The only producer VALU is the 16 multiplies of K by the scale per tile (they fit the MFMA wave's stall gaps).
+template <int D, int QT>
+__global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restrict__ qkv, float *__restrict__ out,
+                                                           int heads, int T, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STAGE = KV * KP + D * VP;
+    const int bh = blockIdx.y;                      // sample*heads + head
+    const int b = bh / heads, head = bh % heads;
+    const float *qp = qkv + ((size_t)b * heads * 3 * D + (size_t)head * 3 * D) * T;
+    const float *kp = qp + (size_t)D * T;
+    const float *vp = qp + (size_t)2 * D * T;
+    const int ntiles = (T + KV - 1) / KV;
+
+    if (threadIdx.x >= 256) {
+        // ------------------------------------------------------------------ producers
+        const int tid = threadIdx.x - 256;
+        for (int it = 0; it < ntiles; ++it) {
+            const int s0 = it * KV;
+            float *k_lds = smem + (it & 1) * STAGE, *v_lds = k_lds + KV * KP;
+            float kr[(D * KV) / 256], vr[(D * KV) / 256];
+#pragma unroll
+            for (int e = 0; e < (D * KV) / 256; ++e) {
+                const int idx = tid + e * 256;
+                const int c = idx / KV, s = idx % KV;
+                const bool ok = (s0 + s) < T;
+                const size_t g = (size_t)c * T + min(s0 + s, T - 1);
+                kr[e] = ok ? kp[g] : 0.0f;
+                vr[e] = ok ? vp[g] : 0.0f;
+            }
+            // stage (it&1) was last read for tile it-2, which the consumers finished before the previous hand-over
+#pragma unroll
+            for (int e = 0; e < (D * KV) / 256; ++e) {
+                const int idx = tid + e * 256;
+                const int c = idx / KV, s = idx % KV;
+                k_lds[s * KP + c] = kr[e] * scale;
+                v_lds[c * VP + s] = vr[e];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int t0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
+    constexpr int HP = D / 2;
+    float qreg[QT][HP];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int t = t0 + qt * 32 + l31;
+#pragma unroll
+        for (int p = 0; p < HP; ++p) qreg[qt][p] = t < T ? qp[(size_t)(lh * HP + p) * T + t] * scale : 0.0f;
+    }
+    constexpr int CB = D / 32;
+    f32x16 o[QT][CB];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qt][cb][r] = 0.0f;
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.0f; }
+
+    for (int it = 0; it < ntiles; ++it) {
+        const int s0 = it * KV;
+        __syncthreads();                           // hand-over: stage (it&1) is complete
+        const float *k_lds = smem + (it & 1) * STAGE, *v_lds = k_lds + KV * KP;
+#pragma unroll
+        for (int sb = 0; sb < KV / 32; ++sb) {
+            if (s0 + sb * 32 >= T) break;          // wave-uniform
+            f32x16 sacc[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[qt][r] = 0.0f;
+            const float *krow = k_lds + (sb * 32 + l31) * KP + lh * HP;
+#pragma unroll
+            for (int g = 0; g < HP / 4; ++g) {
+                const f32x4 kv = *reinterpret_cast<const f32x4 *>(krow + g * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        sacc[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[j], qreg[qt][g * 4 + j], sacc[qt], 0, 0, 0);
+            }
+            const bool ragged = s0 + sb * 32 + 32 > T;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                if (ragged) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (s0 + sb * 32 + crow(r, lh) >= T) sacc[qt][r] = -INFINITY;
+                }
+                float mx = sacc[qt][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[qt][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[qt], mx);
+                const float mb = -m_new * LOG2E;
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * LOG2E);
+                float rs = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[qt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[qt][r], LOG2E, mb));
+                    rs += sacc[qt][r];
+                }
+                rs += __shfl_xor(rs, 32, 64);
+                l_run[qt] = l_run[qt] * alpha + rs;
+                m_run[qt] = m_new;
+                if (__any(alpha != 1.0f)) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qt][cb][r] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const float *vrow = v_lds + (cb * 32 + l31) * VP + sb * 32 + 4 * lh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4 *>(vrow + 8 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt)
+                            o[qt][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j], sacc[qt][4 * g + j], o[qt][cb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float *op = out + ((size_t)b * heads * D + (size_t)head * D) * T;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int t = t0 + qt * 32 + l31;
+        if (t < T) {
+            const float inv = 1.0f / l_run[qt];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = cb * 32 + crow(r, lh);
+                    op[(size_t)c * T + t] = o[qt][cb][r] * inv;
+                }
+        }
+    }
+}
+
 }  // namespace
 
 namespace ipdm {
@@ -186,18 +342,33 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
     if (d != 64 && d != 32) { set_error("attention: head dim %d unsupported (kernel is specialised for 64 and 32)", d); return IPDM_ERR_UNSUPPORTED; }
     // scale = 1/sqrt(sqrt(C/heads)) (Model/model.py:149); python double -> f32 scalar
     const float scale = (float)(1.0 / sqrt(sqrt((double)d)));
-    // 64 queries per wave (K/V operand reads shared by two query tiles: 105 vs 93 TFLOP/s at T=4096) when the 256-query
-    // workgroups still fill the 512 resident slots evenly; a ragged second round (T=7125: 896 workgroups) costs more
-    // than the sharing gains, and small T keeps 32 queries per wave so that the chip stays filled
-    const long wg2 = (long)cdiv(T, 256) * B * heads;
-    const bool q2 = wg2 >= 512 && (wg2 % 512 == 0 || wg2 >= 4 * 512);
-    dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads);
     const bool prof = prof_enabled();
     if (prof) prof_before(2, st);
-    if (d == 64) {
+    static const bool legacy = getenv("IPDM_ATTN_LEGACY") != nullptr;
+    if (d == 64 && !legacy) {
+        // wave-specialised kernel, one 512-thread workgroup per CU.  64 queries per consumer wave (K/V operand reads
+        // shared by two query tiles) when the 256-query workgroups come in whole rounds of the CUs, else 32
+        constexpr size_t lds = (size_t)2 * (KV * KP + 64 * VP) * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)attention_ws_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)attention_ws_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        const long wg2 = (long)cdiv(T, 256) * B * heads, wg1 = (long)cdiv(T, 128) * B * heads;
+        const auto eff = [](long wg) { return (double)wg / (double)(((wg + 255) / 256) * 256); };    // round quantisation
+        const bool q2 = wg2 >= 256 && eff(wg2) >= eff(wg1) - 0.03;
+        dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads);
+        if (q2) hipLaunchKernelGGL((attention_ws_kernel<64, 2>), grid, dim3(512), lds, st, qkv, out, heads, T, scale);
+        else hipLaunchKernelGGL((attention_ws_kernel<64, 1>), grid, dim3(512), lds, st, qkv, out, heads, T, scale);
+    } else if (d == 64) {
+        const long wg2 = (long)cdiv(T, 256) * B * heads;
+        const bool q2 = wg2 >= 512 && (wg2 % 512 == 0 || wg2 >= 4 * 512);
+        dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads);
         if (q2) hipLaunchKernelGGL((attention_kernel<64, 2>), grid, dim3(256), 0, st, qkv, out, heads, T, scale);
         else hipLaunchKernelGGL((attention_kernel<64, 1>), grid, dim3(256), 0, st, qkv, out, heads, T, scale);
     } else {
+        dim3 grid(cdiv(T, 128), B * heads);
         hipLaunchKernelGGL((attention_kernel<32, 1>), grid, dim3(256), 0, st, qkv, out, heads, T, scale);
     }
     if (prof) prof_after(2, 4.0 * B * heads * (double)T * T * d, st);
