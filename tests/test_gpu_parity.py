@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI of libipdm_hip.so) against the CPU oracle and
 the golden vectors of the imported reference.  Tolerances are absolute unless noted and written
 next to each check; north_star: 1e-5 max-abs on the FBP index map, 1e-4 relative PSNR end to end."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -510,3 +512,56 @@ def test_drop_in_sparse_sample_method():
     den.update_opt(dict(sample_method_img="nonsense"))
     with pytest.raises(ValueError):
         den.img_denoiser(out)
+
+
+# =========================================================================== BASELINE.json's full sizes
+FULL_IMG = dict(in_channels=1, model_channels=64, out_channels=1, attention_resolutions=(8, 16), channel_mult=(1, 1, 2, 2, 4, 4))
+FULL_PROJ = dict(in_channels=1, model_channels=64, out_channels=1, attention_resolutions=(16, 32),
+                 channel_mult=(1 / 16, 1 / 8, 1 / 4, 2, 2, 4, 4))
+
+
+@pytest.mark.parametrize("which", ["img", "proj"])
+def test_unet_true_size_vs_oracle(which):
+    """The production UNets at their TRUE input sizes (512x512 / 2000x912; attention over T=4096 / 7125 keys,
+    persistent multi-round conv schedules, the narrow-layer kernels at 2000x912) against the CPU oracle."""
+    kw, shape = (FULL_IMG, (1, 1, 512, 512)) if which == "img" else (FULL_PROJ, (1, 1, 2000, 912))
+    net, sd = _native_unet(kw, 6)
+    x = torch.from_numpy(synth.hash_normal(shape, 401))
+    got = net(x.to(DEV), 13).cpu()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    want = ou.unet_forward(ou.UNetConfig(**kw), sd, x, 13)
+    err = (got - want).abs().max().item()
+    assert err <= 5e-5 * max(1.0, want.abs().max().item()), err
+
+
+def test_full_size_pipeline_psnr():
+    """End to end at full size with the production architectures (few steps so that the CPU oracle finishes in about a
+    minute): proj loop with adaptive guidance -> FBP -> sharpen -> img loop.  north_star's acceptance metric: PSNR
+    against the ground-truth phantom within 1e-4 relative of the CPU path on identical inputs and noise."""
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, _RecordingNoise
+    from ipdm_pytorch_amd.diffusion import NoiseSource
+    from oracle import pipeline as op
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    cfg_load(dict(device=DEV, t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=False), opt.__dict__)
+    den = progressive_domain_denoiser(opt, seed=17)          # full-size UNets, deterministic synthetic weights (seed 0)
+    sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(4)), seed=4)
+    den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
+    rec = _RecordingNoise(NoiseSource(17, 0))
+    den.noise = rec
+    got = den.progressive_denoiser(sharpen_num=70).cpu().numpy()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    cfg_p, cfg_i = ou.UNetConfig(**FULL_PROJ), ou.UNetConfig(**FULL_IMG)
+    sd_p = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_p), seed=0).items()}
+    sd_i = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_i), seed=0).items()}
+    draws = iter([z.cpu() for z in rec.draws])
+    want, _ = op.progressive_slice(dict(opt.__dict__), cfg_p, sd_p, cfg_i, sd_i, torch.from_numpy(sino)[None, None],
+                                   lambda: next(draws), sharpen_num=70)
+    want = want.numpy()
+    assert got.shape == want.shape == (1, 1, 512, 512)
+    assert np.abs(got - want).max() <= 5e-4 * max(1.0, np.abs(want).max())
+    truth = od.miu2pixel(torch.from_numpy(synth.rasterize(synth.ellipse_phantom(4)))).numpy()
+    p_hip = od.psnr(truth, od.miu2pixel(torch.from_numpy(got[0, 0])).numpy())
+    p_cpu = od.psnr(truth, od.miu2pixel(torch.from_numpy(want[0, 0])).numpy())
+    assert abs(p_hip - p_cpu) <= 1e-4 * abs(p_cpu), (p_hip, p_cpu)
