@@ -19,12 +19,12 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(GnArgs a)
         const int c = g * cpg + cc;
         const float *src = (c < a.C1) ? a.x1 + ((size_t)n * a.C1 + c) * a.HW : a.x2 + ((size_t)n * a.C2 + (c - a.C1)) * a.HW;
         const long nv = ((a.HW & 3) == 0 && ((size_t)src & 15) == 0) ? a.HW / 4 : 0;
-        for (long i = (long)s * 256 + threadIdx.x; i < nv; i += (long)GN_SPLIT * 256) {
+        for (long i = (long)s * 256 + threadIdx.x; i < nv; i += (long)a.split * 256) {
             float4 v = reinterpret_cast<const float4 *>(src)[i];
             sum += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
             sq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
         }
-        for (long i = nv * 4 + (long)s * 256 + threadIdx.x; i < a.HW; i += (long)GN_SPLIT * 256) {
+        for (long i = nv * 4 + (long)s * 256 + threadIdx.x; i < a.HW; i += (long)a.split * 256) {
             float v = src[i];
             sum += v;
             sq += (double)v * v;
@@ -48,8 +48,8 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(GnArgs a)
     const int Ctot = a.C1 + a.C2;
     const int cpg = Ctot / a.groups;
     const double *p = a.partials + ((size_t)n * a.groups + g) * GN_SPLIT * 2;
-    double s = threadIdx.x < GN_SPLIT ? p[threadIdx.x * 2] : 0.0;
-    double q = threadIdx.x < GN_SPLIT ? p[threadIdx.x * 2 + 1] : 0.0;
+    double s = threadIdx.x < a.split ? p[threadIdx.x * 2] : 0.0;
+    double q = threadIdx.x < a.split ? p[threadIdx.x * 2 + 1] : 0.0;
     s = wave_sum(s);
     q = wave_sum(q);
     s = __shfl(s, 0, 64);
@@ -79,8 +79,15 @@ int gn_stats_launch(const GnArgs &a, hipStream_t st)
     IPDM_REQUIRE(a.x1 && a.gamma && a.beta && a.partials && a.scale && a.shift, "gn_stats: null argument");
     IPDM_REQUIRE(a.groups > 0 && (a.C1 + a.C2) % a.groups == 0, "gn_stats: %d channels not divisible by %d groups",
                  a.C1 + a.C2, a.groups);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_SPLIT, a.groups, a.B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(64), 0, st, a);
+    // workgroups per (sample, group): enough to stream a large group at HBM speed, but at least ~8k elements each (the
+    // 63x29 / 32x32 layers would otherwise launch 8192 workgroups of two elements per thread); the partial sums are
+    // combined in a fixed order for any split, so results do not depend on it beyond fp64 rounding of the partials
+    GnArgs b = a;
+    const long per_group = (long)((a.C1 + a.C2) / a.groups) * a.HW;
+    int split = (int)((per_group + 8191) / 8192);
+    b.split = split < 1 ? 1 : (split > GN_SPLIT ? GN_SPLIT : split);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(b.split, a.groups, a.B), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(64), 0, st, b);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }

@@ -55,6 +55,7 @@ struct GnArgs {
     float eps;
     double *partials;            // [B, groups, GN_SPLIT, 2]
     float *scale, *shift;        // [B, C1+C2]
+    int split = 0;               // workgroups per (sample, group), chosen by the launcher (<= GN_SPLIT)
 };
 constexpr int GN_SPLIT = 32;
 size_t gn_partials_bytes(int B, int groups);
