@@ -365,7 +365,9 @@ int conv_weight_interleave(int Cout, int ks, int stride)
 {
     static const bool legacy = getenv("IPDM_CONV_LEGACY") != nullptr;
     static const bool legacy1 = getenv("IPDM_CONV1X1_LEGACY") != nullptr;
-    if (legacy || stride != 1 || Cout <= 32 || (ks != 3 && ks != 1) || (ks == 1 && legacy1)) return 0;
+    static const bool legacy2 = getenv("IPDM_CONVS2_LEGACY") != nullptr;
+    if (legacy || Cout <= 32 || (ks != 3 && ks != 1) || (ks == 1 && (legacy1 || stride != 1)) || stride > 2 || (stride == 2 && legacy2))
+        return 0;
     return Cout > 96 ? 4 : 2;       // 128-cout tiles (MB=4,NB=2) for the wide layers, 64-cout x 16-row tiles (MB=2,NB=4) otherwise
 }
 

@@ -540,6 +540,9 @@ int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
         return launch_ws<3, 1, 4, 2, 8>(a, st, 0);
     }
     if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 2) return launch_ws<3, 1, 2, 4, 8>(a, st, 0);
+    // Downsample (3x3 stride 2): same kernel, input tile (2*TH+1) x 65 per channel
+    if (a.ksize == 3 && a.stride == 2 && a.w_interleave == 4) return launch_ws<3, 2, 4, 2, 8>(a, st, 1);
+    if (a.ksize == 3 && a.stride == 2 && a.w_interleave == 2) return launch_ws<3, 2, 2, 2, 8>(a, st, 1);
     // 1x1: a plain GEMM over channels; 32-channel chunks give the producers 8k cycles of MFMA per hand-over
     if (a.ksize == 1 && a.stride == 1 && a.w_interleave == 4) return launch_ws<1, 1, 4, 2, 32>(a, st, 1);
     if (a.ksize == 1 && a.stride == 1 && a.w_interleave == 2) return launch_ws<1, 1, 2, 4, 32>(a, st, 1);
