@@ -565,3 +565,49 @@ def test_full_size_pipeline_psnr():
     p_hip = od.psnr(truth, od.miu2pixel(torch.from_numpy(got[0, 0])).numpy())
     p_cpu = od.psnr(truth, od.miu2pixel(torch.from_numpy(want[0, 0])).numpy())
     assert abs(p_hip - p_cpu) <= 1e-4 * abs(p_cpu), (p_hip, p_cpu)
+
+
+def test_result_dicts_with_saved_states():
+    """save_it_state_proj / save_it_state_img / save_proj_state=True: every stored iterate (ResultTempDict 'iter_k',
+    Utils/train_test_utils.py:459-479,541-548) against the oracle's intermediates, incl. the FBP of EVERY proj iterate."""
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG, _RecordingNoise
+    from ipdm_pytorch_amd.diffusion import NoiseSource
+    from ipdm_pytorch_amd.unet import UNetModel
+    from oracle import pipeline as op, fbp as of
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    cfg_load(dict(device=DEV, t_start_proj=[2, 2], t_start_img=[2, 1], ultra_img_denoise=False, save_it_state_proj=True,
+                  save_it_state_img=True), opt.__dict__)
+    den = progressive_domain_denoiser(opt, seed=9)
+    den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
+    den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
+    sd_p = synth.synth_state_dict(den.proj_model._shapes, seed=21)
+    sd_i = synth.synth_state_dict(den.img_model._shapes, seed=22)
+    den.proj_model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_p.items()})
+    den.img_model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_i.items()})
+    sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(5)), seed=5)
+    den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
+    rec = _RecordingNoise(NoiseSource(9, 0))
+    den.noise = rec
+    out = den.progressive_denoiser(save_proj_state=True, sharpen_num=42)
+    cfg_p = ou.UNetConfig(1, 16, 1, attention_resolutions=(16,), channel_mult=(0.25, 0.25, 0.5, 1, 2, 4), num_heads=1)
+    cfg_i = ou.UNetConfig(1, 16, 1, attention_resolutions=(8,), channel_mult=(1, 1, 2, 2, 4), num_heads=1)
+    draws = iter([z.cpu() for z in rec.draws])
+    want, mid = op.progressive_slice(dict(opt.__dict__), cfg_p, {k: torch.from_numpy(v) for k, v in sd_p.items()}, cfg_i,
+                                     {k: torch.from_numpy(v) for k, v in sd_i.items()}, torch.from_numpy(sino)[None, None],
+                                     lambda: next(draws), sharpen_num=42)
+    # proj iterates: 2 passes + their mean = 3 entries, each also converted by FBP
+    assert len(den.proj_denoise_result) == len(mid["proj"]) == 3
+    assert len(den.proj_denoise_convert2img_result) == 3
+    geo = of.FBPGeometry()
+    for k in range(3):
+        np.testing.assert_allclose(den.proj_denoise_result[k + 1], mid["proj"][k].numpy(), rtol=0, atol=2e-4)
+        fbp_k = of.convert(geo, mid["proj"][k][:, 0].numpy())[:, None]
+        np.testing.assert_allclose(den.proj_denoise_convert2img_result[k + 1], fbp_k, rtol=0, atol=2e-4 * max(1.0, np.abs(fbp_k).max()))
+    # img iterates: 2 passes + mean
+    assert len(den.progressive_denoise_result) == len(mid["img"]) == 3
+    for k in range(3):
+        np.testing.assert_allclose(den.progressive_denoise_result[k + 1], mid["img"][k].numpy(), rtol=0, atol=3e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=0, atol=3e-4)
+    assert den.progressive_denoise_result[-1] is den.progressive_denoise_result["iter_3"]
