@@ -124,12 +124,6 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     const int S = n_my * nchunks;                  // chunks in this workgroup's stream
     const int plane_bytes = a.Hs * a.Ws * 4;
 
-    // De-phase the workgroups: identical tiles keep all 256 CUs in lockstep, so every CU would burst its tile's
-    // stores (32-131 KB) at the same instant and the consumers would sit on a full store queue at HBM speed.
-    if (a.dbg >> 8) {
-        const int phase = (a.dbg & 32) ? (blockIdx.x & 7) : ((blockIdx.x >> 3) & 7);
-        for (int i = 0; i < phase * (a.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
-    }
     if (threadIdx.x >= 256) {
         // =========================================================================== PRODUCERS
         // Addressing is VALU-free: buffer loads take a per-thread byte offset that is constant for a tile (input) or
@@ -422,7 +416,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
             // every quad of lanes (DPP quad_perm + select, 8-16 VALU per block) turns that into 4 consecutive PIXELS of one
             // cout per lane, so one buffer_store_dwordx4 replaces four dword stores (the store path retires ~1 instruction
             // per 100 cycles per wave regardless of its width) and a half-wave still writes 4 full 128-byte row segments.
-            if ((a.Wo & 3) == 0 && t.co0 + T::BN <= a.Cout && !(a.dbg & 64)) {
+            if ((a.Wo & 3) == 0 && t.co0 + T::BN <= a.Cout) {
                 const int qi = l31 & 3, qp = l31 >> 2;
                 const int lane_off4 = ((qi + 4 * lk) * out_plane + 4 * qp) * 4;
                 const bool xok = t.ox0 + 4 * qp + 4 <= a.Wo;
@@ -495,8 +489,9 @@ int launch_ws(const ConvArgs &args, hipStream_t st, int prof_cls)
     using T = WsTile<KS, STRIDE, MB, NB, KC, IL>;
     static_assert(T::LDS_BYTES <= 160 * 1024, "conv_ws: LDS stages exceed 160 KiB");
     ConvArgs a = args;
+    // IPDM_CONV_DBG=8: in-kernel s_memtime stamps per phase (tools/bench_conv_dbg.py; needs a.dbg_buf, bench entry only)
     static const int dbg = getenv("IPDM_CONV_DBG") ? atoi(getenv("IPDM_CONV_DBG")) : 0;
-    a.dbg = dbg;
+    a.dbg = a.dbg_buf ? (dbg & 8) : 0;
     a.tiles_x = cdiv(a.Wo, T::TW);
     a.tiles_y = cdiv(a.Ho, T::TH);
     a.co_tiles = cdiv(a.Cout, T::BN);

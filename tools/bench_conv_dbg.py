@@ -12,6 +12,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         B, C1, C2, H, W, Co, ks, st, act, res = c
         print("  %-40s %7.3f ms %6.1f TF/s" % (c, ms.value, 2.0 * B * H * W * Co * (C1 + C2) * ks * ks / ms.value / 1e9))
 else:
-    for dbg in sys.argv[1:] or ["0", "1", "2", "3", "4"]:
+    for dbg in sys.argv[1:] or ["8"]:
         print("IPDM_CONV_DBG=%s" % dbg, flush=True)
         subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, IPDM_CONV_DBG=dbg))
