@@ -40,15 +40,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-template <int KS, int STRIDE, int MB, int NB, int KC_, int IL = MB>   // IL: cout interleave of the packed weights (>= MB)
+// IL: cout interleave of the packed weights (>= MB).  PBW: the 32 pixels of one MFMA operand are PBW columns x 32/PBW rows
+// (32x1 by default; 8x4 for image widths with a large remainder modulo 32: 228, 114)
+template <int KS, int STRIDE, int MB, int NB, int KC_, int IL = MB, int PBW = 32>
 struct WsTile {
     static constexpr int KC = KC_;
     static constexpr int TAPS = KS * KS;
-    static constexpr int TH = 4 * NB;
-    static constexpr int TW = 32;
+    static constexpr int PBH = 32 / PBW;
+    static constexpr int TH = 4 * NB * PBH;
+    static constexpr int TW = PBW;
     static constexpr int IN_ROWS = (TH - 1) * STRIDE + KS;
     static constexpr int IN_COLS = (TW - 1) * STRIDE + KS;
-    static constexpr int IN_CH = IN_ROWS * IN_COLS;
+    // LDS row pitch: the PBH lane rows of an operand read must fall on disjoint banks (pitch = 8 or 24 mod 32)
+    static constexpr int PITCH = PBW == 32 ? IN_COLS : (IN_COLS <= 8 ? 8 : (IN_COLS <= 24 ? 24 : 40));
+    static constexpr int IN_CH = IN_ROWS * PITCH;
     static constexpr int SP = (IN_CH + 255) / 256;           // staging slots per producer thread per channel
     static constexpr int IN_CHP = SP * 256;                  // LDS channel pitch: every (thread, slot) owns an address
     static constexpr int IN_TILE = KC * IN_CHP;
@@ -102,10 +107,10 @@ __device__ inline f32x2 gn_silu2(f32x2 x, float sc, float sh)
     return z * e;
 }
 
-template <int KS, int STRIDE, int MB, int NB, int KC, int IL>
+template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4>
 __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
 {
-    using T = WsTile<KS, STRIDE, MB, NB, KC, IL>;
+    using T = WsTile<KS, STRIDE, MB, NB, KC, IL, PBW>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     // ---- static tile schedule: at step k the G workgroups cover tiles [kG,(k+1)G); the workgroups of one XCD
@@ -155,9 +160,9 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
 #pragma unroll
                     for (int j = 0; j < T::SP; ++j) {
                         const int sp = tid + j * 256;
-                        const int r = sp / T::IN_COLS, c = sp % T::IN_COLS;
+                        const int r = sp / T::PITCH, c = sp % T::PITCH;
                         const int iy = iy0 + r, ix = ix0 + c;
-                        in_ok[j] = sp < T::IN_CH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                        in_ok[j] = sp < T::IN_CH && c < T::IN_COLS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
                         int sy = min(max(iy, 0), a.H - 1), sx = min(max(ix, 0), a.W - 1);
                         if (a.upsample) {   // F.interpolate(mode="nearest"): src = min(floor(dst * (in/out) in f32), in-1)
                             sy = min((int)floorf((float)sy * a.scale_y), a.Hs - 1);
@@ -256,7 +261,9 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     // =============================================================================== CONSUMERS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lk = lane >> 5, l31 = lane & 31;
-    constexpr int ROWS = (NB - 1) * STRIDE + KS;
+    constexpr int PBH = T::PBH;
+    constexpr int ROWS = (NB - 1) * PBH * STRIDE + KS;          // input rows (per lane row ly) one wave's accumulators touch
+    const int lx = l31 % PBW, ly = l31 / PBW;                      // the lane's pixel inside its PBW x PBH block
     constexpr int NP = KC / 2;
 
     f32x16 acc[MB][NB];
@@ -269,7 +276,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     // scalar offset per (cout, row); anything outside the sample's [Cout][Ho][Wo] block is dropped by the range check.
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     const int out_plane = a.Ho * a.Wo;
-    const int lane_off = (lk * 4 * out_plane + l31) * 4;
+    const int lane_off = (lk * 4 * out_plane + ly * a.Wo + lx) * 4;      // lane part: cout half, block row, block column
     // bias (conv bias + time-embedding projection) is added by one MFMA per accumulator after the last K chunk; the MB
     // bias values of the NEXT tile are fetched right after, a whole tile ahead of their use.
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
@@ -307,7 +314,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 for (int r = 0; r < ROWS; ++r)
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx)
-                        Bv[r][kx] = ib[c * T::IN_CHP + (wave * NB * STRIDE + r) * T::IN_COLS + l31 * STRIDE + kx];
+                        Bv[r][kx] = ib[c * T::IN_CHP + ((wave * NB * PBH + ly) * STRIDE + r) * T::PITCH + lx * STRIDE + kx];
             };
             auto read_a = [&](int cp, int t, float (&A)[MB]) __attribute__((always_inline)) {
                 const int c = cp * 2 + lk;
@@ -330,7 +337,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
                         for (int q = 0; q < NB; ++q)
-                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[m], b_cur[q * STRIDE + t / KS][t % KS], acc[m][q], 0, 0, 0);
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[m], b_cur[q * PBH * STRIDE + t / KS][t % KS], acc[m][q], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < MB; ++m) a_c[m] = a_n[m];
@@ -366,8 +373,8 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
             int voffq[NB], rowq[NB];
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-                const int oy = t.oy0 + swave * NB + q;
-                voffq[q] = (t.ox0 + l31 < a.Wo && oy < a.Ho) ? lane_off : OOB;
+                const int oy = t.oy0 + (swave * NB + q) * PBH;          // first row of the block; the lane adds ly
+                voffq[q] = (t.ox0 + lx < a.Wo && oy + ly < a.Ho) ? lane_off : OOB;
                 rowq[q] = (min(oy, a.Ho - 1) * a.Wo + t.ox0) * 4;     // scalar offsets stay in range; the lanes are killed above
             }
             // PARTIAL: the tile's couts run past Cout (Cout % (32*MB) != 0): those registers are skipped by a scalar
@@ -376,26 +383,22 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 constexpr bool PARTIAL = decltype(partial_tag)::value;
                 auto co_ok = [&](int m, int r) { return !PARTIAL || t.co0 + m * 32 + (r & 3) + 8 * (r >> 2) < a.Cout; };
                 if (a.res) {
-                    // residual first, as its own phase (loads two groups deep): VMEM loads and stores retire through one
-                    // in-order counter, so a load issued behind stores would wait for those stores to reach memory
-                    float rv[2][16];
-                    auto load_group = [&](int m, int q, float (&dst)[16]) __attribute__((always_inline)) {
-                        int so = (t.co0 + m * 32) * plane4 + rowq[q];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            dst[r] = co_ok(m, r) ? bload(r_rsrc, voffq[q], so) : 0.0f;
-                            so += ((r & 3) == 3 ? 5 : 1) * plane4;
-                        }
-                    };
-                    load_group(0, 0, rv[0]);
+                    // residual first, as its own phase: VMEM loads and stores retire through one in-order counter, so a
+                    // load issued behind stores would wait for those stores to reach memory
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
                         for (int q = 0; q < NB; ++q) {
-                            const int idx = m * NB + q;
-                            if (idx + 1 < MB * NB) load_group((idx + 1) / NB, (idx + 1) % NB, rv[(idx + 1) & 1]);
+                            float rv[16];
+                            int so = (t.co0 + m * 32) * plane4 + rowq[q];
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[m][q][r] += rv[idx & 1][r];
+                            for (int r = 0; r < 16; ++r) {
+                                rv[r] = co_ok(m, r) ? bload(r_rsrc, voffq[q], so) : 0.0f;
+                                so += ((r & 3) == 3 ? 5 : 1) * plane4;
+                                asm volatile("" : "+s"(so));       // keep ONE running scalar offset (no table of 128 SGPRs)
+                            }
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[m][q][r] += rv[r];
                         }
                 }
 #pragma unroll
@@ -408,6 +411,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                             const float v = acc[m][q][r];      // (bit_cast straight from the vector element stores element 0)
                             if (co_ok(m, r)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, voffq[q], so, 0);
                             so += ((r & 3) == 3 ? 5 : 1) * plane4;
+                            asm volatile("" : "+s"(so));
                         }
                     }
             };
@@ -416,13 +420,14 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
             // every quad of lanes (DPP quad_perm + select, 8-16 VALU per block) turns that into 4 consecutive PIXELS of one
             // cout per lane, so one buffer_store_dwordx4 replaces four dword stores (the store path retires ~1 instruction
             // per 100 cycles per wave regardless of its width) and a half-wave still writes 4 full 128-byte row segments.
-            if ((a.Wo & 3) == 0 && t.co0 + T::BN <= a.Cout) {
-                const int qi = l31 & 3, qp = l31 >> 2;
-                const int lane_off4 = ((qi + 4 * lk) * out_plane + 4 * qp) * 4;
-                const bool xok = t.ox0 + 4 * qp + 4 <= a.Wo;
+            if constexpr (VEC4) {       // launcher: Wo % 4 == 0 and Cout % (32*MB) == 0
+                const int qi = l31 & 3;
+                const int qx = lx >> 2;                                    // quad of 4 consecutive columns inside the block row
+                const int lane_off4 = ((qi + 4 * lk) * out_plane + ly * a.Wo + 4 * qx) * 4;
+                const bool xok = t.ox0 + 4 * qx + 4 <= a.Wo;
                 int voff4[NB];
 #pragma unroll
-                for (int q = 0; q < NB; ++q) voff4[q] = (xok && t.oy0 + swave * NB + q < a.Ho) ? lane_off4 : OOB;
+                for (int q = 0; q < NB; ++q) voff4[q] = (xok && t.oy0 + (swave * NB + q) * PBH + ly < a.Ho) ? lane_off4 : OOB;
                 const bool odd = (l31 & 1) != 0, hi = (l31 & 2) != 0;
 #define IPDM_XCHG(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
                 auto block = [&](int m, int q, int g) __attribute__((always_inline)) -> f32x4 {
@@ -458,8 +463,10 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4[q], so + 8 * g * plane4, 0);
                         }
                     }
-            } else if (t.co0 + T::BN <= a.Cout) epilogue(std::false_type{});
-            else epilogue(std::true_type{});
+            } else {
+                if (t.co0 + T::BN <= a.Cout) epilogue(std::false_type{});
+                else epilogue(std::true_type{});
+            }
         }
         if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_epi += now - t_last; t_last = now; }
     }
@@ -483,10 +490,10 @@ int num_cus()
     return n;
 }
 
-template <int KS, int STRIDE, int MB, int NB, int KC, int IL = MB>
-int launch_ws(const ConvArgs &args, hipStream_t st, int prof_cls)
+template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4>
+int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
 {
-    using T = WsTile<KS, STRIDE, MB, NB, KC, IL>;
+    using T = WsTile<KS, STRIDE, MB, NB, KC, IL, PBW>;
     static_assert(T::LDS_BYTES <= 160 * 1024, "conv_ws: LDS stages exceed 160 KiB");
     ConvArgs a = args;
     // IPDM_CONV_DBG=8: in-kernel s_memtime stamps per phase (tools/bench_conv_dbg.py; needs a.dbg_buf, bench entry only)
@@ -507,16 +514,26 @@ int launch_ws(const ConvArgs &args, hipStream_t st, int prof_cls)
     G = (G + 7) / 8 * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL>,
+        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
         attr_set = true;
     }
     const bool prof = prof_enabled();
     if (prof) prof_before(prof_cls, st);
-    hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL>), dim3((unsigned)G), dim3(512), T::LDS_BYTES, st, a, (int)ntiles);
+    hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>), dim3((unsigned)G), dim3(512), T::LDS_BYTES, st, a, (int)ntiles);
     if (prof) prof_after(prof_cls, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
+}
+
+// the 16-byte-store epilogue needs whole runs of 4 pixels per row and whole cout tiles; everything else takes the
+// dword epilogue (with its ragged-cout variant).  Two kernels instead of one keep either epilogue out of the other's
+// register allocation.
+template <int KS, int STRIDE, int MB, int NB, int KC, int IL = MB, int PBW = 32>
+int launch_ws(const ConvArgs &a, hipStream_t st, int prof_cls)
+{
+    if ((a.Wo & 3) == 0 && a.Cout % (32 * MB) == 0) return launch_ws_v<KS, STRIDE, MB, NB, KC, IL, PBW, true>(a, st, prof_cls);
+    return launch_ws_v<KS, STRIDE, MB, NB, KC, IL, PBW, false>(a, st, prof_cls);
 }
 
 }  // namespace
@@ -532,6 +549,8 @@ int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
         // over the same packed weights: 4x the workgroups, each reading its half of the 128-cout interleave group
         const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128) * a.B;
         if (tiles < 160) return launch_ws<3, 1, 2, 1, 8, 4>(a, st, 0);
+        // (8x4-pixel MFMA blocks -- PBW = 8, tile 32 rows x 8 cols -- pad the 228/114-wide layers 8 % less but measured
+        // 3-9 % SLOWER: 32-byte row pieces in every load and store, 18 instead of 12 operand reads per channel pair)
         return launch_ws<3, 1, 4, 2, 8>(a, st, 0);
     }
     if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 2) return launch_ws<3, 1, 2, 4, 8>(a, st, 0);
