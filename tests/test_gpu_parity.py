@@ -308,6 +308,28 @@ def test_conv_kernel(case):
     _conv_case(*case, seed=200 + sum(case[:8]))
 
 
+def test_conv_kernel_random_shapes():
+    """40 seeded random convolutions across every kernel family and edge condition at once: channel counts that are not
+    multiples of the chunk / tile sizes, concat splits (aligned to the 8- or 32-channel chunk as the executor
+    guarantees), ragged heights / widths (incl. W % 4 != 0: the dword epilogue), up-sampling to explicit sizes, stride 2,
+    1x1, all three prologues, residual on / off."""
+    rng = np.random.default_rng(20261003)
+    chans = [1, 4, 8, 12, 16, 24, 36, 64, 72, 128, 136, 192, 256]
+    for i in range(40):
+        ks = int(rng.choice([3, 3, 3, 1]))
+        stride = int(rng.choice([1, 1, 1, 2])) if ks == 3 else 1
+        cout = int(rng.choice([1, 4, 8, 16, 24, 40, 64, 96, 128, 200, 256]))
+        c1 = int(rng.choice(chans))
+        c2 = int(rng.choice([0, 0, 8, 64, 128])) if c1 % 32 == 0 else 0
+        act = int(rng.choice([0, 1, 2])) if (c1 + c2) > 1 else 0
+        B = int(rng.integers(1, 4))
+        Hs, Ws = int(rng.integers(5, 70)), int(rng.integers(5, 90))
+        up = stride == 1 and rng.random() < 0.2
+        H, W = (Hs * 2 - int(rng.integers(0, 2)), Ws * 2 - int(rng.integers(0, 2))) if up else (Hs, Ws)
+        res = bool(rng.random() < 0.5)
+        _conv_case(B, c1, c2, Hs, Ws, H, W, cout, ks, stride, act, res, seed=1000 + 17 * i)
+
+
 @pytest.mark.parametrize("B,heads,T", [(1, 1, 35), (2, 4, 117), (1, 4, 1024), (1, 2, 1827), (1, 1, 7125)])
 def test_attention_kernel(B, heads, T):
     from ipdm_pytorch_amd import _lib
@@ -320,6 +342,23 @@ def test_attention_kernel(B, heads, T):
     attn = torch.einsum("bct,bcs->bts", (q * scale).double(), (k * scale).double()).softmax(dim=-1)
     want = torch.einsum("bts,bcs->bct", attn, v.double()).reshape(B, heads * d, T).float()
     assert (out.cpu() - want).abs().max() <= 2e-5
+
+
+def test_attention_random_lengths():
+    """Seeded random (B, heads, T): every ragged-tail length class of the 64-key tiles and 128/256-query workgroups."""
+    from ipdm_pytorch_amd import _lib
+    rng = np.random.default_rng(7)
+    d = 64
+    for T in [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511] + [int(v) for v in rng.integers(300, 2200, 6)]:
+        B, heads = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        qkv = torch.from_numpy(synth.hash_normal((B, heads * 3 * d, T), 900 + T)) * float(rng.uniform(0.3, 2.0))
+        out = torch.full((B, heads * d, T), float("nan"), device=DEV)
+        _lib.call("ipdm_op_attention", _lib.ptr(qkv.to(DEV)), _lib.ptr(out), B, heads, d, T, _lib.current_stream())
+        q, k, v = qkv.reshape(B * heads, 3 * d, T).chunk(3, dim=1)
+        scale = 1.0 / np.sqrt(np.sqrt(d))
+        attn = torch.einsum("bct,bcs->bts", (q * scale).double(), (k * scale).double()).softmax(dim=-1)
+        want = torch.einsum("bts,bcs->bct", attn, v.double()).reshape(B, heads * d, T).float()
+        assert (out.cpu() - want).abs().max() <= 2e-5, (B, heads, T)
 
 
 def test_attention_softmax_rescale_branch():
