@@ -233,21 +233,23 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                             v = a.act == 2 ? gn_silu2(v, sc, sh) : v * sc + sh;
                             raw[c][T::SP - 1] = v[0];
                         }
-                    }
-                    if (border) {      // zero padding is re-imposed AFTER the activation (border tiles only)
+                        // each channel goes to LDS as soon as it is transformed: the stores (not VALU) issue beside the
+                        // next channel's math instead of forming a tail of the window; zero padding is re-imposed AFTER
+                        // the activation (border tiles only)
 #pragma unroll
-                        for (int c = 0; c < KC; ++c)
-#pragma unroll
-                            for (int j = 0; j < T::SP; ++j) raw[c][j] = in_ok[j] ? raw[c][j] : 0.0f;
+                        for (int j = 0; j < T::SP; ++j)
+                            dst[c * T::IN_CHP + j * 256] = (!border || in_ok[j]) ? raw[c][j] : 0.0f;
                     }
-                    if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_math += now - p_t; p_t = now; }
+                    if (pstamp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                  const unsigned long long now = __builtin_amdgcn_s_memtime(); p_math += now - p_t; p_t = now; }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < KC; ++c)
+#pragma unroll
+                        for (int j = 0; j < T::SP; ++j) dst[c * T::IN_CHP + j * 256] = raw[c][j];
+                    if (pstamp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                  const unsigned long long now = __builtin_amdgcn_s_memtime(); p_store += now - p_t; p_t = now; }
                 }
-#pragma unroll
-                for (int c = 0; c < KC; ++c)
-#pragma unroll
-                    for (int j = 0; j < T::SP; ++j) dst[c * T::IN_CHP + j * 256] = raw[c][j];
-                if (pstamp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                              const unsigned long long now = __builtin_amdgcn_s_memtime(); p_store += now - p_t; p_t = now; }
                 __syncthreads();                           // hand-over: stage (s&1) is complete
             }
         }
