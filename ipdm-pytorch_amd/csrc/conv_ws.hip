@@ -10,23 +10,28 @@
 //   * waves 0-3 (one per SIMD) are CONSUMERS: nothing but ds_read + MFMA + the tile epilogue.  Their
 //     instruction stream never touches global memory inside the K loop, so the matrix pipe of each SIMD is
 //     fed back-to-back by a single wave whose LDS operands are fetched one tap ahead;
-//   * waves 4-7 (the SIMD partners of 0-3) are PRODUCERS: they issue the global loads of the NEXT K chunk
-//     (which may belong to the next tile), apply GroupNorm/SiLU + zero padding and fill the other LDS
-//     stage while the consumers compute -- VALU/VMEM work co-issues beside the partner's MFMAs;
+//   * waves 4-7 (the SIMD partners of 0-3) are PRODUCERS: they issue the buffer loads of the NEXT K chunk
+//     (which may belong to the next tile) with VALU-free addressing and fill the other LDS stage while the
+//     consumers compute -- VMEM / LDS / SALU work issues beside the partner's MFMAs for free;
 //   * one workgroup barrier per K chunk hands the stage over; the chunk stream runs across tile
 //     boundaries, so there is no per-tile prologue bubble and the epilogue stores of tile i drain while
 //     tile i+1 is already being multiplied.
 //
 // Tile = (4*NB rows) x 32 cols of output pixels x (32*MB) couts; consumer wave w owns rows
-// [w*NB,(w+1)*NB).  LDS per stage: input halo tile [KC][IN_ROWS][IN_COLS] + weight slab [KC][taps][32][MB].
+// [w*NB,(w+1)*NB).  LDS per stage: input halo tile [KC][IN_ROWS][IN_COLS] + weight slab [KC][taps][32][IL].
 //
-// Issue model measured on MI355X (tools/ubench/coissue.hip): v_mfma_f32_32x32x2_f32 holds its OWN wave's issue
-// for the full 64 cycles (every ds_read / s_waitcnt / VALU op of the consumer is additive, ~9 cycles), while the
-// partner wave on the SIMD issues beside it at ~25 cycles per VALU op and 16 per ds_write without slowing the MFMA
-// stream.  Hence: (i) big register tiles (MB*NB = 8 accumulators) and ONE wide LDS read per tap for the weights
-// (the slab is stored cout-interleaved so the MB values of a lane are adjacent: ds_read_b64/b128) keep the
-// consumer at ~0.2 LDS instructions per MFMA; (ii) a chunk carries 18k cycles of MFMA work, twice what the
-// producers need for their ~250 slow-issuing instructions plus one global-load latency.
+// Issue model measured on MI355X (tools/ubench/coissue.hip): v_mfma_f32_32x32x2_f32 occupies the
+// SIMD's vector ALU for its whole 64 cycles.  Every other instruction of the MFMA wave is additive (~9 cycles); a
+// partner wave's LDS / VMEM / SALU ops issue freely, but its VALU ops only get the MFMA wave's own stall gaps
+// (~280 cycles per op under a saturated stream, at any priority).  Hence:
+//   (i)   8 accumulators per consumer wave and ONE wide LDS read per tap for the weights (the slab is stored
+//         cout-interleaved, so the MB values of a lane are adjacent: ds_read_b64/b128): 0.3 LDS instructions per MFMA;
+//   (ii)  producers do no address arithmetic on the VALU (buffer loads: one per-lane offset per tile + scalar offsets;
+//         out-of-range offsets implement the zero padding);
+//   (iii) the one unavoidable VALU job, GroupNorm(+SiLU) of the staged tile, runs as a burst in a short window in
+//         which the consumers wait at a barrier (~800 cycles per 18.4k-cycle chunk) instead of starving;
+//   (iv)  bias is one MFMA per accumulator after the last chunk; the epilogue transposes 4x4 blocks inside lane quads
+//         (DPP) so that stores and residual loads move 16 bytes per lane.
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
