@@ -186,6 +186,10 @@ int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches);
 int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, int32_t W, int32_t Cout, int32_t ksize,
                       int32_t stride, int32_t act, int32_t with_res, int32_t iters, float *avg_ms);
 int ipdm_bench_attention(int32_t B, int32_t heads, int32_t d, int32_t T, int32_t iters, float *avg_ms);
+/* Which kernel family a convolution of this shape is packed for NOW (the environment switches are read when
+ * weights are packed): 0 = plain layout (direct / legacy kernels), 2 | 4 = conv_ws cout-interleaved f32 MFMA,
+ * 102 | 103 = opt-in split-bf16 (IPDM_CONV_SPLIT=2|3).  Test aid: lets a parity test prove which path it ran. */
+int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
 
 #ifdef __cplusplus
 }

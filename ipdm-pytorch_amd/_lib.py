@@ -75,6 +75,7 @@ PROTOTYPES = {
     "ipdm_bench_conv2d": (C.c_int, [_i32] * 11 + [C.POINTER(_f32)]),
     "ipdm_bench_attention": (C.c_int, [_i32] * 5 + [C.POINTER(_f32)]),
     "ipdm_op_attention": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ipdm_conv_layout_code": (_i32, [_i32, _i32, _i32]),
 }
 
 _lib = None

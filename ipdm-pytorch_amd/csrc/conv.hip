@@ -348,6 +348,7 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
     const bool wide = a.Cout > 32;
     // wide 3x3 convolutions (>80 % of the path's FLOPs) run on the persistent wave-specialised kernel (conv_ws.hip);
     // when their weights were packed for it (conv_weight_interleave); IPDM_CONV_LEGACY=1 at pack time keeps them here
+    if (conv_sx_pieces(a.w_interleave)) return conv2d_sx_launch(a, st);
     if (a.w_interleave) return conv2d_ws_launch(a, st);
     static const bool no_direct = getenv("IPDM_CONV_NO_DIRECT") != nullptr;
     if (!no_direct && conv_direct_eligible(a)) return conv2d_direct_launch(a, st);
@@ -359,13 +360,18 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
 }
 
 int conv_k_chunk() { return 8; }
-int conv_ws_k_chunk(int ks, int interleave) { return (interleave && ks == 1) ? 32 : 8; }
+int conv_ws_k_chunk(int ks, int interleave) { return conv_sx_pieces(interleave) ? 16 : ((interleave && ks == 1) ? 32 : 8); }
 
 int conv_weight_interleave(int Cout, int ks, int stride)
 {
     static const bool legacy = getenv("IPDM_CONV_LEGACY") != nullptr;
     static const bool legacy1 = getenv("IPDM_CONV1X1_LEGACY") != nullptr;
     static const bool legacy2 = getenv("IPDM_CONVS2_LEGACY") != nullptr;
+    // IPDM_CONV_SPLIT=3 (6-term, fp32-equivalent) or 2 (3-term): opt-in split-bf16 evaluation of the wide 3x3 stride-1 convs
+    // (read at every pack, not cached: one process may hold nets of both modes -- bench.py's alt leg, the split parity tests)
+    const char *split_env = getenv("IPDM_CONV_SPLIT");
+    const int split = split_env ? atoi(split_env) : 0;
+    if (!legacy && (split == 2 || split == 3) && ks == 3 && stride == 1 && Cout > 32) return 100 + split;
     if (legacy || Cout <= 32 || (ks != 3 && ks != 1) || (ks == 1 && (legacy1 || stride != 1)) || stride > 2 || (stride == 2 && legacy2))
         return 0;
     return Cout > 96 ? 4 : 2;       // 128-cout tiles (MB=4,NB=2) for the wide layers, 64-cout x 16-row tiles (MB=2,NB=4) otherwise
@@ -377,6 +383,10 @@ int conv_weight_interleave(int Cout, int ks, int stride)
 void conv_pack_weights(const float *w, int Cout, int Cin, int ks, int interleave, std::vector<float> &packed, int &cin_pad,
                        int &cout_pad)
 {
+    if (conv_sx_pieces(interleave)) {
+        conv_sx_pack_weights(w, Cout, Cin, conv_sx_pieces(interleave), packed, cin_pad, cout_pad);
+        return;
+    }
     const int group = interleave ? 32 * interleave : 64;
     const int kc = conv_ws_k_chunk(ks, interleave);           // channels per K chunk of the kernel that will read the slab
     cin_pad = (Cin + kc - 1) / kc * kc;

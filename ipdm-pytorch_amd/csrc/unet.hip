@@ -634,6 +634,7 @@ struct Fwd {
         if (x2 && !layers.empty() && layers[0].kind == L_RES) {
             const ResP &rp0 = net->res[layers[0].prefix];
             if (rp0.has_sc) align = std::max(align, conv_ws_k_chunk(1, rp0.sc.interleave));
+            align = std::max(align, conv_ws_k_chunk(3, rp0.c1.interleave));
         }
         if (x2 && (x1->C % align) != 0) {
             // the conv kernel walks K in chunks that must not straddle the two sources: materialise torch.cat
@@ -871,6 +872,11 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     (void)hipFree(d_w); (void)hipFree(d_x1); (void)hipFree(d_x2); (void)hipFree(d_out); (void)hipFree(d_res); (void)hipFree(d_sc);
     (void)hipFree(d_sh); (void)hipFree(d_b); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
+}
+
+extern "C" int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride)
+{
+    return conv_weight_interleave(Cout, ksize, stride);
 }
 
 extern "C" int ipdm_bench_attention(int32_t B, int32_t heads, int32_t d, int32_t T, int32_t iters, float *avg_ms)

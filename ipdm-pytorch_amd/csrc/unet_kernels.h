@@ -29,6 +29,10 @@ struct ConvArgs {
 
 int conv2d_launch(const ConvArgs &a, hipStream_t st);
 int conv2d_ws_launch(const ConvArgs &a, hipStream_t st);   // persistent wave-specialised variant (conv_ws.hip)
+// opt-in split-bf16 evaluation of the wide 3x3 convolutions (conv_sx.hip); weight layout code 100 + pieces
+int conv_sx_pieces(int interleave);
+void conv_sx_pack_weights(const float *w, int Cout, int Cin, int ns, std::vector<float> &packed, int &cin_pad, int &cout_pad);
+int conv2d_sx_launch(const ConvArgs &a, hipStream_t st);
 bool conv_direct_eligible(const ConvArgs &a);             // narrow layers: direct packed-f32 VALU kernel (conv_direct.hip)
 int conv2d_direct_launch(const ConvArgs &a, hipStream_t st);
 int conv_k_chunk();   // concat inputs must split at a multiple of this many channels (3x3 kernels)

@@ -396,6 +396,41 @@ def test_unet_small_golden(tag, golden):
         np.testing.assert_allclose(got, g["%s_t%d" % (tag, t)], rtol=0, atol=1e-5)
 
 
+@pytest.fixture
+def split_bf16(monkeypatch):
+    """Opt-in split-bf16 evaluation of the wide 3x3 convolutions (read when weights are packed)."""
+    def on(pieces):
+        from ipdm_pytorch_amd import _lib
+        monkeypatch.setenv("IPDM_CONV_SPLIT", str(pieces))
+        assert _lib.lib().ipdm_conv_layout_code(64, 3, 1) == 100 + pieces      # the split kernel is what runs
+        assert _lib.lib().ipdm_conv_layout_code(64, 3, 2) in (2, 4) and _lib.lib().ipdm_conv_layout_code(16, 3, 1) == 0
+    return on
+
+
+@pytest.mark.parametrize("case", [
+    (2, 64, 0, 32, 32, 32, 32, 64, 3, 1, 2, True),
+    (1, 128, 64, 16, 32, 16, 32, 64, 3, 1, 2, False),
+    (1, 72, 0, 21, 35, 21, 35, 200, 3, 1, 2, True),         # ragged cin chunk and ragged cout tile
+    (1, 48, 0, 29, 63, 57, 125, 40, 3, 1, 0, False),        # up-sample, odd width (dword epilogue)
+    (1, 256, 0, 40, 48, 40, 48, 256, 3, 1, 2, True),
+])
+def test_conv_kernel_split_bf16_x6(case, split_bf16):
+    """3-piece split-bf16 (6 MFMA terms, f32 accumulate) meets the SAME tolerance as the exact-f32 kernel."""
+    split_bf16(3)
+    _conv_case(*case, seed=4200 + sum(case[:8]))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_unet_small_golden_split_bf16_x6(tag, golden, split_bf16):
+    split_bf16(3)
+    g = golden("unet_small")
+    net, sd = _native_unet(SMALL_CFGS[tag], 11)
+    x = torch.from_numpy(synth.hash_normal(SMALL_SHAPES[tag], 101))
+    for t in (0, 7):
+        got = net(x.to(DEV), torch.full((1,), t, dtype=torch.long)).cpu().numpy()
+        np.testing.assert_allclose(got, g["%s_t%d" % (tag, t)], rtol=0, atol=1e-5)
+
+
 def test_unet_head_dim_unsupported_fails_loudly():
     from ipdm_pytorch_amd import IpdmError
     net, _ = _native_unet(SMALL_CFGS["c"], 11)
