@@ -61,7 +61,7 @@ struct GnArgs {
     float *scale, *shift;        // [B, C1+C2]
     int split = 0;               // workgroups per (sample, group), chosen by the launcher (<= GN_SPLIT)
 };
-constexpr int GN_SPLIT = 32;
+constexpr int GN_SPLIT = 64;
 size_t gn_partials_bytes(int B, int groups);
 int gn_stats_launch(const GnArgs &a, hipStream_t st);
 

@@ -185,7 +185,16 @@ class progressive_domain_denoiser:
             model=self.proj_model, img=x.to(self.proj_device, torch.float32), t_start=o.t_start_proj, clip=o.clip_proj,
             lambda_ratio=o.lambda_ratio_proj, eta=o.eta_proj, mode="proj", constant_guidance=o.constant_guidance_proj,
             kernel_size_proj=o.kernel_size_proj, amplitude_proj=o.amplitude_proj, only_convertor=o.benchmark_test,
-            normal=o.normal, noise=self._noise())
+            normal=o.normal, noise=self._noise(), rank_max=self._rank_max())
+
+    def _rank_max(self):
+        """Adaptive pass schedule (t_start_proj=None) under slice sharding: the branch is taken on the maximum over
+        ALL ranks' slices, as the reference takes it over its whole batch (Model/model.py:596-609)."""
+        import torch.distributed as td
+        if not (td.is_available() and td.is_initialized() and td.get_world_size() > 1):
+            return None
+        from . import dist as idist
+        return lambda v: idist.max_over_ranks(v, self.proj_device)
 
     def _img_dense(self, x, noise_strength, ultra):
         o = self.opt

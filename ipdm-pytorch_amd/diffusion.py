@@ -208,6 +208,11 @@ class GaussianDiffusion:
                     Lam, emax = self.guidance_map(x, img, "proj", kwargs["kernel_size_proj"], kwargs["amplitude_proj"])
                     if adaptive:
                         m = float(emax.max().item())       # the one device->host scalar of adaptive mode
+                        # the reference decides on the whole batch's maximum (delt.max(), :596-609); when the batch is
+                        # sharded over ranks the decision must not depend on the sharding: `rank_max` (a scalar MAX
+                        # all-reduce, handed in by the denoiser under torch.distributed) makes it global again
+                        if kwargs.get("rank_max") is not None:
+                            m = float(kwargs["rank_max"](m))
                         if m >= 30:
                             t_list, noise_strength, eta = [30, 25, 20], "high", 0.6
                         elif m >= 4.5:

@@ -37,6 +37,18 @@ SPARSE_CASES = {
                                         condition_lambda_min=0.3, eta=0.6, clip_denoised=True, ddim_eta=0.3)),
 }
 
+# adaptive pass schedule (t_start=None, Model/model.py:532-536,582-613,639-640): (mode, shape, schedule power,
+# amplitude, noise_strength handed in, kwargs).  proj picks its branch from delt.max() (amplitude chosen well inside
+# each branch: low <4.5, mid [4.5,30), high >=30) and reports it; img takes the branch from `noise_strength`.
+ADAPT_CASES = {
+    "proj_low": ("proj", (1, 1, 40, 24), 5, 7, None, dict(clip=False, lambda_ratio=1, eta=0.5)),
+    "proj_mid": ("proj", (1, 1, 40, 24), 5, 20, None, dict(clip=False, lambda_ratio=1, eta=0.5)),
+    "proj_high": ("proj", (1, 1, 40, 24), 5, 45, None, dict(clip=True, lambda_ratio=1, eta=0.5)),
+    "img_high": ("img", (1, 1, 32, 32), 1, 30, "high", dict(clip=True, lambda_ratio=10, eta=0.7)),
+    "img_mid": ("img", (1, 1, 32, 32), 1, 30, "mid", dict(clip=True, lambda_ratio=10, eta=0.7)),
+    "img_none": ("img", (1, 1, 32, 32), 1, 30, None, dict(clip=False, lambda_ratio=10, eta=0.7)),
+}
+
 
 class noise_feed:
     """Hashed N(0,1) draws in call order: draw k of feed `seed` = hash_normal(shape, seed*1000+k)."""

@@ -181,6 +181,36 @@ def gen_loops():
     save("loops", **out)
 
 
+# ------------------------------------------------------------------ 6a. adaptive pass schedule (t_start=None)
+def gen_adaptive():
+    from tests.golden.cases import ADAPT_CASES
+    out = {}
+    net, _ = ref_unet(LOOP_CFG, seed=41)
+    curves = {"img": U.curve_init(), "proj": U.proj_curv_init()}
+    orig = torch.randn_like
+    try:
+        for tag, (mode, shape, power, amp, ns_in, kw) in ADAPT_CASES.items():
+            gd = M.GaussianDiffusion(timesteps=1000, beta_schedule="cosine", schedule_power=power)
+            if mode == "img":
+                img = torch.from_numpy(synth.hash_uniform(shape, 42)) * 0.05 + 0.17
+            else:
+                img = torch.from_numpy(synth.hash_uniform(shape, 43)) * 0.6
+            ldct = torch.from_numpy(synth.hash_uniform(shape, 44)) * 0.05 + 0.17
+            feed = _NoiseFeed(48)
+            torch.randn_like = feed
+            res, _, ns = gd.guided_reverse_process(
+                model=net, img=img, mode=mode, t_start=None, save_states=False, lambda_curve=curves[mode], ldct=ldct,
+                kernel_size_img=4, amplitude_img=amp, kernel_size_proj=4, amplitude_proj=amp, only_convertor=False,
+                normal=False, noise_strength=ns_in, transformer=None, constant_guidance=None, **kw)
+            out[tag] = np.stack([r.numpy() for r in res])
+            out[tag + "_ndraws"] = np.array(feed.k)
+            out[tag + "_ns"] = np.array(str(ns))
+            print("  adaptive %-10s draws %3d noise_strength %s" % (tag, feed.k, ns))
+    finally:
+        torch.randn_like = orig
+    save("adaptive", **out)
+
+
 # ------------------------------------------------------------------ 6b. sparse_guided_reverse_process (DDIM)
 def gen_sparse():
     out = {}
@@ -297,6 +327,7 @@ if __name__ == "__main__":
     gen_ops()
     gen_step()
     gen_loops()
+    gen_adaptive()
     gen_sparse()
     gen_misc()
     gen_fbp()

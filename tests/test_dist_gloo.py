@@ -35,6 +35,11 @@ def _worker(rank, world, port, n_slices, q):
     out = idist.all_gather_slices(local, n_slices, r, w)
     want = _per_slice_work(full, 0)
     t = idist.max_over_ranks(1.0 + rank, "cpu")
+    # adaptive pass schedule (t_start_proj=None): every rank must take the branch of the GLOBAL Delta-map maximum
+    import types
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser
+    hook = progressive_domain_denoiser._rank_max(types.SimpleNamespace(proj_device="cpu"))
+    assert hook is not None and hook(3.0 if rank == 0 else 40.0) == 40.0
     idist.barrier()
     q.put((rank, bool(torch.equal(out, want)), tuple(out.shape), t, (lo, hi)))
     torch.distributed.destroy_process_group()

@@ -481,6 +481,31 @@ def test_guided_reverse_process_golden(golden):
         np.testing.assert_allclose(got, g[tag], rtol=0, atol=5e-5)
 
 
+def test_adaptive_pass_schedule_golden(golden):
+    """t_start=None (Model/model.py:532-536,582-613,639-640) through the C ABI: branch taken,
+    noise_strength returned, draws consumed and iterates against the reference's own run."""
+    from ipdm_pytorch_amd.diffusion import GaussianDiffusion, InjectedNoise
+    from tests.golden.cases import ADAPT_CASES
+    g = golden("adaptive")
+    net, _ = _native_unet(LOOP_CFG, 41)
+    for tag, (mode, shape, power, amp, ns_in, kw) in ADAPT_CASES.items():
+        gd = GaussianDiffusion(1000, "cosine", power)
+        img = (torch.from_numpy(synth.hash_uniform(shape, 42)) * 0.05 + 0.17) if mode == "img" else \
+            torch.from_numpy(synth.hash_uniform(shape, 43)) * 0.6
+        ldct = torch.from_numpy(synth.hash_uniform(shape, 44)) * 0.05 + 0.17
+        nd = int(g[tag + "_ndraws"])
+        noise = InjectedNoise([torch.from_numpy(synth.hash_normal(shape, 48 * 1000 + k)) for k in range(nd)])
+        res, _, ns = gd.guided_reverse_process(
+            model=net, img=img.to(DEV), t_start=None, mode=mode, lambda_curve=None, ldct=ldct.to(DEV), kernel_size_img=4,
+            amplitude_img=amp, kernel_size_proj=4, amplitude_proj=amp, only_convertor=False, normal=False,
+            noise_strength=ns_in, constant_guidance=None, noise=noise, **kw)
+        assert str(ns) == str(g[tag + "_ns"]), tag
+        assert noise.draw == nd, tag
+        got = np.stack([r.cpu().numpy() for r in res])
+        assert got.shape == g[tag].shape
+        np.testing.assert_allclose(got, g[tag], rtol=0, atol=1e-4, err_msg=tag)
+
+
 def test_sparse_guided_reverse_process_golden(golden):
     """sample_method='sparse' (DDIM, Model/model.py:654-759) through the C ABI against the reference's outputs."""
     from ipdm_pytorch_amd.diffusion import GaussianDiffusion, InjectedNoise, NoiseSource
@@ -586,6 +611,47 @@ def test_drop_in_sparse_sample_method():
     den.update_opt(dict(sample_method_img="nonsense"))
     with pytest.raises(ValueError):
         den.img_denoiser(out)
+
+
+def test_drop_in_adaptive_schedule_hand_off():
+    """t_start_proj=None / t_start_img=None (Utils/train_test_utils.py:553-566): the proj pass picks the branch from the
+    Delta map, reports noise_strength, and the img pass takes its pass list from that hand-off (4 iterates each:
+    3 adaptive passes + the final average, the t=20 probe pass dropped, Model/model.py:639-640)."""
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG
+    from ipdm_pytorch_amd.unet import UNetModel
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    den = progressive_domain_denoiser(opt, seed=5)
+    den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
+    den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
+    for m, seed in ((den.proj_model, 21), (den.img_model, 22)):
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(m._shapes, seed=seed).items()})
+    calls = {"proj": 0, "img": 0}
+
+    class counted:
+        def __init__(self, net, name):
+            self.net, self.name = net, name
+
+        def __call__(self, x, t):
+            calls[self.name] += 1
+            return self.net(x, t)
+
+        def __getattr__(self, k):
+            return getattr(self.net, k)
+    den.proj_model, den.img_model = counted(den.proj_model, "proj"), counted(den.img_model, "img")
+    den.update_opt(dict(t_start_proj=None, t_start_img=None, constant_guidance_img=None, ultra_img_denoise=False,
+                        save_it_state_proj=True, save_it_state_img=True))
+    sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(2)), seed=2)
+    den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
+    out = den.progressive_denoiser(sharpen_num=70, save_proj_state=True)
+    assert tuple(out.shape) == (1, 1, 512, 512) and bool(torch.isfinite(out).all())
+    want_proj = {"high": 20 + 75, "mid": 20 + 53, "low": 20 + 45}
+    want_img = {"high": 20 + 45, "mid": 20 + 37, "low": 20 + 30}
+    assert den.noise_strength in want_proj
+    assert calls["proj"] == want_proj[den.noise_strength] and calls["img"] == want_img[den.noise_strength], calls
+    assert len(den.proj_denoise_result) == 4 and len(den.proj_denoise_convert2img_result) == 4
+    assert len(den.progressive_denoise_result) == 4
 
 
 # =========================================================================== BASELINE.json's full sizes

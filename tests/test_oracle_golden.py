@@ -8,7 +8,7 @@ from oracle import fbp as of
 from oracle import unet as ou
 from ipdm_pytorch_amd import synth
 
-from tests.golden.cases import SPARSE_CASES, SMALL_CFGS, SMALL_SHAPES, LOOP_CFG, LOOP_CASES, noise_feed
+from tests.golden.cases import ADAPT_CASES, SPARSE_CASES, SMALL_CFGS, SMALL_SHAPES, LOOP_CFG, LOOP_CASES, noise_feed
 
 
 def test_schedule_tables(golden):
@@ -97,6 +97,28 @@ def test_guided_reverse_process(golden):
         assert feed.count == int(g[tag + "_ndraws"])       # same number of randn draws as the reference
         got = np.stack([r.numpy() for r in res])
         np.testing.assert_allclose(got, g[tag], rtol=0, atol=5e-6)
+
+
+def test_adaptive_pass_schedule(golden):
+    """t_start=None (Model/model.py:532-536,582-613,639-640): the pass list chosen after pass 0, the reported
+    noise_strength, the draw count and the iterates, against the reference's own run."""
+    g = golden("adaptive")
+    cfg = ou.UNetConfig(**LOOP_CFG)
+    sd, _ = _sd(cfg, 41)
+    for tag, (mode, shape, power, amp, ns_in, kw) in ADAPT_CASES.items():
+        sch = od.Schedule(1000, power)
+        img = (torch.from_numpy(synth.hash_uniform(shape, 42)) * 0.05 + 0.17) if mode == "img" else \
+            torch.from_numpy(synth.hash_uniform(shape, 43)) * 0.6
+        ldct = torch.from_numpy(synth.hash_uniform(shape, 44)) * 0.05 + 0.17
+        feed = noise_feed(48, shape)
+        res, ns = od.guided_reverse_process_slice(
+            sch, lambda x, t: ou.unet_forward(cfg, sd, x, t), img, t_start=None, mode=mode, constant_guidance=None,
+            noise_fn=feed, ldct=ldct, kernel_size=4, amplitude=amp, noise_strength_in=ns_in, **kw)
+        assert str(ns) == str(g[tag + "_ns"]), tag
+        assert feed.count == int(g[tag + "_ndraws"]), tag
+        got = np.stack([r.numpy() for r in res])
+        assert got.shape == g[tag].shape
+        np.testing.assert_allclose(got, g[tag], rtol=0, atol=1e-5, err_msg=tag)
 
 
 def test_sparse_guided_reverse_process(golden):
