@@ -174,6 +174,40 @@ int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, int32_t C2,
 int ipdm_op_attention(const float *d_qkv, float *d_out, int32_t B, int32_t heads, int32_t d, int32_t T,
                       void *stream);
 
+/* ------------------------------------------------------------------ ART convertor ------------ */
+/* SART over a triangle-area lookup table + its forward projector: convertor="ART" and self.projection of the
+ * reference (Utils/train_test_utils.py:225-233) = Recon/TASART2DNSL0 recons_torch / proj_torch
+ * (TASART2DNSL0_PyAPI.cpp:33-80 -> TASART2DNSL0.cu DoReconstruction :721-975 / DoProjection :1335-1438).
+ * SURVEY section 8(f) rank 3.  Geometry = the `Parameters` struct (TASART2DNSL0.h:23-42). */
+typedef struct ipdm_art_geom {
+    float dso, dsd;
+    int32_t nx, ny;
+    float dx, dy, offset_x, offset_y;
+    int32_t nr;
+    float dr, offset_r, angle_start;
+    int32_t na, ta_dimx, ta_dimy;      /* na = number of view angles in `betas` */
+    float ta_deltax, ta_deltay;
+} ipdm_art_geom;
+typedef struct ipdm_art_plan ipdm_art_plan;
+/* lut_area_host: [ta_dimy][ta_dimx] f32 (Recon/Simens_alut.txt), betas_host: [na] view angles in degrees
+ * (Recon/Simens_theta.txt) -- the two arrays recons_torch / proj_torch take.  Uploads them, precomputes the bin-edge
+ * rays of every view (update_lines_kernel, .cu:270-302) and the per-view normalisation projection (_Fp_Ax(norm_proj,
+ * footinfo, 1.0f), .cu:871).  Allocates and synchronises. */
+int ipdm_art_plan_create(const ipdm_art_geom *geom, const float *lut_area_host, const float *betas_host,
+                         ipdm_art_plan **out);
+int ipdm_art_plan_destroy(ipdm_art_plan *plan);
+size_t ipdm_art_workspace_bytes(const ipdm_art_plan *plan, int32_t B);
+/* recons_torch(h_proj, lut_area, betas, nstart, ntv, sample_rate, permute): d_proj [B, na, nr] -> d_volume [B, ny, nx]
+ * (NOT permuted: the caller applies permute(0,2,1) as a view, PyAPI.cpp:55-57).  sample_rate > 1 uses the first
+ * na / sample_rate views and rows, as the reference does (PyAPI.cpp:37).  Asynchronous on `stream`; the whole
+ * reconstruction (nsart sweeps of one launch per view + the NSL0-TV steps, all scalars kept on the device) issues no
+ * host synchronisation. */
+int ipdm_art_reconstruct(ipdm_art_plan *plan, const float *d_proj, float *d_volume, int32_t B, int32_t nsart,
+                         int32_t ntv, int32_t sample_rate, void *d_ws, size_t ws_bytes, void *stream);
+/* proj_torch(h_volume, lut_area, betas): d_volume [B, ny, nx] -> d_proj [B, na, nr] */
+int ipdm_art_project(ipdm_art_plan *plan, const float *d_volume, float *d_proj, int32_t B, void *d_ws,
+                     size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------ measurement ------------- */
 /* Per-launch HIP-event timing of the hot kernels on their launch stream (bench.py roofline leg; no
  * reference counterpart -- the reference has no profiling).  Classes: 0 = conv 3x3

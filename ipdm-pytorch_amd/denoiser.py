@@ -110,13 +110,27 @@ class progressive_domain_denoiser:
                                                          schedule_power=o.schedule_power_proj)
 
     def init_convertor(self, convertor):
+        """Utils/train_test_utils.py:225-233.  The reference reads Recon/Simens_alut.txt / Simens_theta.txt from its
+        working directory; here the two tables are regenerated (art.area_lut / art.view_angles reproduce the files)."""
+        from . import art
+        self._fbp = None
+        self._art = None
         if convertor == "FBP":
             self._fbp = FBP(device=self.opt.device)
             self.convertor = self._fbp.convert
+        elif convertor == "ART":
+            self._art = art._plan_for(*self._art_tables(), torch.device(self.opt.device))
+            self.convertor = lambda x: art.recons_torch(x, *self._art_tables(), nstart=10, ntv=self.opt.ntv,
+                                                        sample_rate=1, permute=True, device=self.opt.device)
         else:
-            # "ART"/"TV": pybind11+libtorch SART-NSL0TV (Recon/TASART2DNSL0-Cpp) -- out of scope
-            self._fbp = None
             self.convertor = None
+        self.projection = lambda x: art.proj_torch(x, *self._art_tables(), device=self.opt.device)
+
+    def _art_tables(self):
+        from . import art
+        if getattr(self, "_art_tab", None) is None:
+            self._art_tab = (art.area_lut(), art.view_angles())
+        return self._art_tab
 
     def load_model(self):
         """Utils/train_test_utils.py:247-251 + LoggerX.load_checkpoints (Utils/loggerx.py:71-80): state_dict
@@ -166,10 +180,12 @@ class progressive_domain_denoiser:
 
     # ------------------------------------------------------------------ device-resident core
     def _convert_dev(self, sino_b1hw, gain):
-        if self._fbp is None:
-            raise NotImplementedError("convertor %r is out of scope: only 'FBP' is built (north_star)"
-                                      % (self.opt.convertor,))
-        return self._fbp.convert_device(sino_b1hw[:, 0], flip=True, gain=gain).unsqueeze(1)
+        if self._fbp is not None:
+            return self._fbp.convert_device(sino_b1hw[:, 0], flip=True, gain=gain).unsqueeze(1)
+        if self._art is not None:       # recons_torch(G * x, nstart=10, ntv, permute=True), :231-232
+            x = sino_b1hw[:, 0] if gain == 1 else sino_b1hw[:, 0] * float(gain)
+            return self._art.reconstruct_device(x, 10, self.opt.ntv).permute(0, 2, 1).contiguous().unsqueeze(1)
+        raise NotImplementedError("convertor %r: only 'FBP' and 'ART' exist" % (self.opt.convertor,))
 
     def _proj_dense(self, x):
         o = self.opt
