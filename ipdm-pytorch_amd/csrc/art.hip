@@ -150,23 +150,25 @@ __device__ __forceinline__ float correction(const SweepArgs &a, int b, int r)
 }
 
 // One SART view: back-project + update for v_prev (if >= 0), footprint + forward projection for v_cur (if >= 0).
-__global__ void __launch_bounds__(256) art_sweep_kernel(SweepArgs a)
+template <int TS>
+__global__ void __launch_bounds__(TS * TS) art_sweep_kernel(SweepArgs a)
 {
     __shared__ unsigned long long win[BMAX * WIN];
     __shared__ float lcorr[BMAX * WIN];
     __shared__ int wmin_s, wminp_s;
     const ArtConst &c = a.c;
-    const int tid = threadIdx.y * 16 + threadIdx.x;
-    const int ix = blockIdx.x * 16 + threadIdx.x, iy = blockIdx.y * 16 + threadIdx.y;
+    constexpr int NT = TS * TS;
+    const int tid = threadIdx.y * TS + threadIdx.x;
+    const int ix = blockIdx.x * TS + threadIdx.x, iy = blockIdx.y * TS + threadIdx.y;
     const bool inside = ix < c.nx && iy < c.ny;
     const int pix = iy * c.nx + ix;
     const long np = (long)c.nx * c.ny;
     // the bins of the launch after this one
-    for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < (long)a.B * c.nr;
-         i += (long)gridDim.x * gridDim.y * 256)
+    for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * NT + tid; i < (long)a.B * c.nr;
+         i += (long)gridDim.x * gridDim.y * NT)
         a.bins_next[i] = 0ULL;
     if (tid == 0) { wmin_s = 0x7fffffff; wminp_s = 0x7fffffff; }
-    for (int i = tid; i < BMAX * WIN; i += 256) win[i] = 0ULL;
+    for (int i = tid; i < BMAX * WIN; i += NT) win[i] = 0ULL;
     float vol[BMAX];
 #pragma unroll
     for (int b = 0; b < BMAX; ++b) vol[b] = (inside && b < a.B) ? a.vol[b * np + pix] : 0.0f;
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(256) art_sweep_kernel(SweepArgs a)
         __syncthreads();
         // the tile's window of corrected bins, formed once per workgroup
         const int w0 = wminp_s < 0 ? 0 : wminp_s;
-        for (int i = tid; i < a.B * WIN; i += 256) {
+        for (int i = tid; i < a.B * WIN; i += NT) {
             const int r = w0 + (i % WIN);
             lcorr[i] = r < c.nr ? correction(a, i / WIN, r) : 0.0f;
         }
@@ -246,7 +248,7 @@ __global__ void __launch_bounds__(256) art_sweep_kernel(SweepArgs a)
         }
     }
     __syncthreads();
-    for (int i = tid; i < a.B * WIN; i += 256) {
+    for (int i = tid; i < a.B * WIN; i += NT) {
         const unsigned long long q = win[i];
         const int is = wmin + (i % WIN);
         if (q != 0ULL && is >= 0 && is < c.nr) atomicAdd(&a.bins_cur[(i / WIN) * c.nr + is], q);
@@ -542,6 +544,10 @@ extern "C" int ipdm_art_reconstruct(ipdm_art_plan *p, const float *d_proj, float
     const long np = (long)c.nx * c.ny;
     const long proj_stride = (long)p->g.na * c.nr;
     const dim3 tiles(cdiv(c.nx, 16), cdiv(c.ny, 16)), blk(16, 16);
+    // 16x16-pixel tiles: 8x8 single-wave workgroups were measured 18 % slower (33 vs 28 us per view at B = 8: four times
+    // the sparse flush atomics and correction-window fills for the same pixels)
+    constexpr int TS = 16;
+    const dim3 stiles(cdiv(c.nx, TS), cdiv(c.ny, TS)), sblk(TS, TS);
     for (int b0 = 0; b0 < B; b0 += BMAX) {
         const int nb = B - b0 < BMAX ? B - b0 : BMAX;
         ArtWs w = carve(p, d_ws, nb);
@@ -561,7 +567,7 @@ extern "C" int ipdm_art_reconstruct(ipdm_art_plan *p, const float *d_proj, float
                 a.bins_prev = w.bins + (size_t)((v + 2) % 3) * bin_n;
                 a.bins_cur = w.bins + (size_t)(v % 3) * bin_n;
                 a.bins_next = w.bins + (size_t)((v + 1) % 3) * bin_n;
-                hipLaunchKernelGGL(art_sweep_kernel, tiles, blk, 0, st, a);
+                hipLaunchKernelGGL(art_sweep_kernel<TS>, stiles, sblk, 0, st, a);
             }
             IPDM_LAUNCH_CHECK();
             hipLaunchKernelGGL(art_sq_partial_kernel, dim3(SQ_BLOCKS, nb), dim3(256), 0, st, w.x_for, w.x_back, np, w.partial);

@@ -320,6 +320,21 @@ def gen_misc():
     save("misc", **out)
 
 
+# ------------------------------------------------------------------ 9. ART data tables
+def gen_art_tables():
+    """Samples of the two data files the ART convertor is driven by (Recon/Simens_alut.txt: the pixel-area table
+    [181, 1501]; Recon/Simens_theta.txt: the 2000 view angles): every 7th angle row x every 13th distance column plus the
+    first / last rows and columns, and every 9th view angle."""
+    ref = os.path.join(os.path.dirname(os.path.dirname(M.__file__)), "Recon")
+    sa = np.fromfile(os.path.join(ref, "Simens_alut.txt"), "float32").reshape(181, 1501)
+    st = np.fromfile(os.path.join(ref, "Simens_theta.txt"), "float32")
+    rows = np.unique(np.concatenate([np.arange(0, 181, 7), [1, 179, 180]]))
+    cols = np.unique(np.concatenate([np.arange(0, 1501, 13), [1, 2, 1498, 1499, 1500]]))
+    save("art_tables", rows=rows, cols=cols, lut=sa[np.ix_(rows, cols)], lut_shape=np.array(sa.shape),
+         lut_sum=np.array(sa.astype(np.float64).sum()), theta_idx=np.arange(0, 2000, 9), theta=st[::9],
+         theta_n=np.array(st.size))
+
+
 if __name__ == "__main__":
     gen_schedule()
     gen_groups()
@@ -331,3 +346,4 @@ if __name__ == "__main__":
     gen_sparse()
     gen_misc()
     gen_fbp()
+    gen_art_tables()
