@@ -33,6 +33,10 @@ _FLAGS = [
     ("amplitude_proj", float, 5, None), ("ddim_timesteps_proj", int, [1, 2, 2], "+"),
     ("sample_method_proj", str, "dense", None), ("save_it_state_proj", bool, False, None),
     ("dose", float, 0.25, None),
+    # whole-dataset evaluation (test()/fit(), Config/default_config.py:19,141-149)
+    ("test_numbers", int, 50, None), ("data_type", str, "siemens", None),
+    ("test_dataset_path_FD_img", str, None, None), ("test_dataset_path_LD_img", str, None, None),
+    ("test_dataset_path_FD_proj", str, None, None), ("test_dataset_path_LD_proj", str, None, None),
 ]
 
 

@@ -17,6 +17,7 @@ from . import _lib
 from .config import cfg_load
 from .diffusion import GaussianDiffusion, NoiseSource
 from .fbp import FBP, tensor_sharpen
+from .evaluate import EvaluationMixin
 from .unet import UNetModel
 
 
@@ -52,7 +53,7 @@ def miu2pixel(miu):
     return img
 
 
-class progressive_domain_denoiser:
+class progressive_domain_denoiser(EvaluationMixin):
     def __init__(self, opt, result_save_path=None, seed=0, slice_id0=0):
         self.opt = opt
         self.opt_temp = copy.deepcopy(opt)
@@ -76,6 +77,10 @@ class progressive_domain_denoiser:
         self.progressive_denoise_result = ResultTempDict()
         self.noise_strength = None
         self.noise = None          # optional NoiseSource / InjectedNoise override (parity tests)
+        # metric bookkeeping and the result tree <result_save_path>/<model>_<run>/save_test_results (:131-133,156-200);
+        # without a result_save_path nothing is created until test() / save_path_load() is asked for
+        self._init_evaluation(None if result_save_path is None else
+                              os.path.join(result_save_path, "%s_%s" % (opt.model_name, opt.run_name)))
 
     # ------------------------------------------------------------------ options (:202-211)
     def update_opt(self, ultra_cfg=None):
@@ -148,6 +153,7 @@ class progressive_domain_denoiser:
     def temp_clear(self):
         self.proj_temp_clear()
         self.img_temp_clear()
+        self.metric_clear()
         self.noise_strength = None
 
     def proj_temp_clear(self):

@@ -1,0 +1,354 @@
+"""Whole-dataset evaluation around the sampling path: the npz dataset reader
+(Dataset/npz_data_loader.py:55-201), the image-quality metrics of `metric_calculate` (Utils/train_test_utils.py:
+792-810), the per-sample / whole-run metric files and result archives (:765-828) and the `test()` / `fit()` drivers
+(:274-348).  Host-side Python, as in the reference; the sampling itself is the HIP path of denoiser.py.
+
+Metrics: the reference calls scikit-image 0.19.3 (psnr, ssim), piq 0.8.0 (vif_p, fsim) and its own Utils/NQM.py.  None of
+the two packages exists in this image, so psnr / ssim / vif_p restate the published algorithms with those versions'
+defaults (the call sites fix win_size=11, data_range=1, chromatic=False); nqm restates Utils/NQM.py and is pinned on
+values computed by the reference's own function (tests/golden/metrics.npz).  fsim (phase congruency over a log-Gabor
+bank with a dozen library-specific constants) is not restated: asking for it raises NotImplementedError.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+from scipy import ndimage
+
+
+# ----------------------------------------------------------------------------------------------- metrics
+def compare_psnr(image_true, image_test, data_range=1):
+    """skimage.metrics.peak_signal_noise_ratio: 10 log10(R^2 / mse), the squared error averaged in float64."""
+    a, b = np.asarray(image_true), np.asarray(image_test)
+    err = np.mean((a - b) ** 2, dtype=np.float64)
+    return 10 * np.log10((data_range ** 2) / err)
+
+
+def compare_ssim(im1, im2, win_size=11, data_range=1, K1=0.01, K2=0.03):
+    """skimage.metrics.structural_similarity with its defaults (uniform window, sample covariance, float32 images stay
+    float32, border of (win_size-1)//2 cropped, mean in float64)."""
+    im1, im2 = np.asarray(im1), np.asarray(im2)
+    ft = np.float32 if (im1.dtype == np.float32 and im2.dtype == np.float32) else np.float64
+    im1, im2 = im1.astype(ft, copy=False), im2.astype(ft, copy=False)
+    npix = win_size ** im1.ndim
+    cov_norm = npix / (npix - 1)
+    f = lambda x: ndimage.uniform_filter(x, size=win_size)     # noqa: E731
+    ux, uy = f(im1), f(im2)
+    uxx, uyy, uxy = f(im1 * im1), f(im2 * im2), f(im1 * im2)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+    pad = (win_size - 1) // 2
+    return S[tuple(slice(pad, -pad) for _ in range(S.ndim))].mean(dtype=np.float64)
+
+
+def _gauss_kernel(n, sigma):
+    c = np.arange(n, dtype=np.float64) - (n - 1) / 2.0
+    g = np.exp(-(c ** 2) / (2 * sigma ** 2))
+    k = np.outer(g, g)
+    return k / k.sum()
+
+
+def _valid_conv(x, k):
+    n = k.shape[0]
+    full = ndimage.correlate(x, k, mode="constant")
+    lo = n // 2
+    return full[lo:x.shape[0] - (n - 1 - lo), lo:x.shape[1] - (n - 1 - lo)]
+
+
+def vif_p(x, y, sigma_n_sq=2.0, data_range=1.0):
+    """Pixel-domain Visual Information Fidelity (Sheikh & Bovik 2006) in the four-scale form piq.vif_p uses:
+    images scaled to [0, 255], Gaussian windows of 17 / 9 / 5 / 3 taps (sigma = taps / 5), valid convolutions, factor-2
+    decimation between scales.  x = reference, y = distorted; 2-D arrays (or [1,1,H,W] tensors)."""
+    x = np.asarray(x, dtype=np.float64).reshape(np.shape(x)[-2:]) / float(data_range) * 255.0
+    y = np.asarray(y, dtype=np.float64).reshape(np.shape(y)[-2:]) / float(data_range) * 255.0
+    eps = 1e-8
+    num = den = 0.0
+    for scale in range(4):
+        n = 2 ** (4 - scale) + 1
+        k = _gauss_kernel(n, n / 5.0)
+        if scale > 0:
+            x, y = _valid_conv(x, k)[::2, ::2], _valid_conv(y, k)[::2, ::2]
+        mu_x, mu_y = _valid_conv(x, k), _valid_conv(y, k)
+        sxx = np.maximum(_valid_conv(x * x, k) - mu_x * mu_x, 0.0)
+        syy = np.maximum(_valid_conv(y * y, k) - mu_y * mu_y, 0.0)
+        sxy = _valid_conv(x * y, k) - mu_x * mu_y
+        g = sxy / (sxx + eps)
+        sv = syy - g * sxy
+        m = sxx < eps
+        g[m], sv[m], sxx[m] = 0.0, syy[m], 0.0
+        m = syy < eps
+        g[m], sv[m] = 0.0, 0.0
+        m = g < 0
+        sv[m], g[m] = syy[m], 0.0
+        sv = np.maximum(sv, eps)
+        num += np.sum(np.log10(1.0 + (g ** 2) * sxx / (sv + sigma_n_sq)))
+        den += np.sum(np.log10(1.0 + sxx / sigma_n_sq))
+    return (num + eps) / (den + eps)
+
+
+def _ctf(f):
+    return 1.0 / (200 * (2.6 * (0.0192 + 0.114 * f) * np.exp(-(0.114 * f) ** 1.1)))
+
+
+def NQM(image_origin, image_query, view_angle=1):
+    """Noise Quality Measure (Damera-Venkata et al. 2000) as Utils/NQM.py computes it: a 5-band cosine-log pyramid in
+    the Fourier domain, contrast masking against the original's band contrasts, global thresholding, then the SNR of the
+    restored pair."""
+    O, I = np.asarray(image_origin), np.asarray(image_query)
+    rows, cols = O.shape
+    xp, yp = np.meshgrid(np.arange(-cols / 2, cols / 2), np.arange(-rows / 2, rows / 2))
+    r = np.abs(xp + 1j * yp)
+
+    def band(rr, lo, hi, fill, shift):
+        inside = (rr >= lo) & (rr <= hi)
+        return 0.5 * (1 + np.cos(np.pi * np.log2(rr * inside + fill * (~inside)) - shift))
+
+    filters = [band(r + 2, 1, 4, 4, np.pi), band(r, 1, 4, 4, np.pi), band(r, 2, 8, .5, 0.0), band(r, 4, 16, 4, np.pi),
+               band(r, 8, 32, .5, 0.0), band(r, 16, 64, 4, np.pi)]
+    FO, FI = np.fft.fft2(O), np.fft.fft2(I)
+    bo = [np.real(np.fft.ifft2(np.fft.fftshift(g) * FO)) for g in filters]      # l_0, a_1..a_5
+    bi = [np.real(np.fft.ifft2(np.fft.fftshift(g) * FI)) for g in filters]
+    y1 = np.zeros_like(bo[0])
+    y2 = np.zeros_like(bo[0])
+    for k in range(1, 6):
+        c = bo[k] / sum(bo[:k])                      # band contrast against everything below it
+        ci = bi[k] / sum(bi[:k])
+        # contrast masking (cmaskn_modified): where the query's contrast is within the masking threshold of the
+        # original's, the query band is replaced by the original band
+        ct = _ctf(k)
+        cic = np.where(np.abs(ci) > 1, 1.0, ci)
+        T = ct * (.86 * ((c / ct) - 1) + .3)
+        ai = np.where((np.abs(cic - c) - T) < 0, bo[k], bi[k])
+        # global thresholding (gthresh_modified) at the contrast sensitivity of the band's centre frequency
+        d = _ctf(2 ** k / view_angle)
+        y1 = y1 + np.where(np.abs(c) < d, 0.0, bo[k])
+        y2 = y2 + np.where(np.abs(ci) < d, 0.0, ai)
+    return 10 * np.log10(np.sum(y1 ** 2) / np.sum((y1 - y2) ** 2))
+
+
+def fsim(*_a, **_k):
+    raise NotImplementedError("fsim (piq 0.8.0) is not restated in this build: drop 'fsim' from opt.metrics")
+
+
+# ----------------------------------------------------------------------------------------------- metric bookkeeping
+def aggregate_metrics(samples):
+    """metric_total_save's arithmetic (Utils/train_test_utils.py:59-118, 812-822): per key the mean over the samples
+    that have it and `<key>_std` = population standard deviation, nested dicts preserved."""
+    def walk(dicts):
+        out = {}
+        keys = []
+        for d in dicts:
+            for k in d:
+                if k not in keys:
+                    keys.append(k)
+        for k in keys:
+            vals = [d[k] for d in dicts if k in d]
+            if isinstance(vals[0], dict):
+                out[k] = walk(vals)
+            else:
+                out[k] = sum(vals) / len(vals)
+        for k in keys:
+            vals = [d[k] for d in dicts if k in d]
+            if not isinstance(vals[0], dict):
+                out[k + "_std"] = (sum((v - out[k]) ** 2 for v in vals) / len(vals)) ** 0.5
+        return out
+    return walk(list(samples))
+
+
+# ----------------------------------------------------------------------------------------------- dataset
+def _split_path(p):
+    """(patient directory, file name) of a dataset file, whichever separator the path was written with (the reference
+    splits on a backslash only, Dataset/npz_data_loader.py:119-126)."""
+    parts = p.replace("\\", "/").split("/")
+    return parts[-2], parts[-1]
+
+
+class Siemens_dataset_npz(torch.utils.data.Dataset):
+    """Dataset/npz_data_loader.py:55-201 for evaluation: four parallel trees `<root>/<patient>/<slice>.npz|npy`
+    (low-dose image, full-dose projection, full-dose image, low-dose projection); item = [ld_img, fd_proj, fd_img,
+    ld_proj] as [1, H, W] tensors (None for trees not given); projections divided by 10 when proj_clip."""
+
+    def __init__(self, ldproj_path=None, ldimg_path=None, fdproj_path=None, fdimg_path=None, proj_clip=False,
+                 img_clip=True, data_type="siemens", patch=None, patch_per_image=None, assign=None):
+        if patch is not None:
+            raise NotImplementedError("random training patches belong to the training loop (out of scope)")
+        self.data_type, self.proj_clip, self.img_clip = data_type, proj_clip, img_clip
+        self.patient_name = self.slice_name = None
+        self.paths = dict(ldimg=ldimg_path, fdproj=fdproj_path, fdimg=fdimg_path, ldproj=ldproj_path)
+        self.files = {}
+        for kind in ("fdimg", "fdproj", "ldimg", "ldproj"):          # the reference's order of precedence for names
+            root = self.paths[kind]
+            if root is None:
+                continue
+            names = sorted(glob.glob(root + "/*/*"))
+            if assign is not None and kind in ("fdimg", "fdproj"):
+                names = [n for n in names if _split_path(n)[0] in assign]
+            self.files[kind] = names
+            if self.patient_name is None:
+                self.patient_name = [_split_path(n)[0] for n in names]
+                pick = 0 if data_type == "siemens" else -4           # mayo names carry the slice four dots from the end
+                self.slice_name = [_split_path(n)[1].split(".")[pick] for n in names]
+
+    @staticmethod
+    def get_data(file_path):
+        arr = np.load(file_path)
+        return arr["arr_0"] if file_path.split(".")[-1] == "npz" else arr
+
+    def _item(self, kind, path):
+        a = self.get_data(path)
+        if kind in ("fdproj", "ldproj") and self.proj_clip:
+            a = a / 10
+        return torch.from_numpy(np.ascontiguousarray(a))[None]       # ToTensor() of a 2-D float array
+
+    def __len__(self):
+        for kind in ("fdimg", "fdproj", "ldimg", "ldproj"):
+            if kind in self.files:
+                return len(self.files[kind])
+        return 0
+
+    def __getitem__(self, idx):
+        return [self._item(k, self.files[k][idx]) if k in self.files else None for k in ("ldimg", "fdproj", "fdimg", "ldproj")]
+
+    def get_data_from_name(self, patient_name, slice_name):
+        out = []
+        for k in ("ldimg", "fdproj", "fdimg", "ldproj"):
+            if k not in self.files:
+                out.append(None)
+                continue
+            hit = [n for n in self.files[k] if patient_name in n and slice_name in n][0]
+            out.append(self._item(k, hit))
+        return out
+
+    @staticmethod
+    def collate(batch):
+        return tuple(torch.stack([b[i] for b in batch], 0) if batch[0][i] is not None else None for i in range(4))
+
+
+# ----------------------------------------------------------------------------------------------- drivers
+class EvaluationMixin:
+    """The evaluation half of progressive_domain_denoiser (Utils/train_test_utils.py:274-348, 596-828)."""
+
+    METRIC_MODES = ("LDCT", "deProj", "deImg", "deProg", "deProj2img")
+
+    def _init_evaluation(self, save_root):
+        from .denoiser import DotDict
+        self.metric_each_sample = []
+        self.metric_total = DotDict()
+        self.metric_clear()
+        self.save_root_path = os.path.join(save_root, "save_test_results") if save_root is not None else None
+        self.save_path = None
+        self.test_dataset = None
+
+    def metric_clear(self):
+        from .denoiser import DotDict
+        self.metric_instance = DotDict({m: DotDict() for m in self.METRIC_MODES})
+
+    def metric_update(self):
+        self.metric_each_sample.append(self.metric_instance)
+
+    def metric_calculate(self, mode="LDCT", **kwargs):
+        i, ld = kwargs["it"], kwargs["denoise_result"]
+        ld[np.isnan(ld)] = 0.5
+        m, want = self.metric_instance[mode], self.opt.metrics
+        if "psnr" in want:
+            m["psnr_iter_%d" % i] = float(compare_psnr(self.fdct, ld, data_range=1))
+        if "ssim" in want:
+            m["ssim_iter_%d" % i] = float(compare_ssim(self.fdct, ld, win_size=11, data_range=1))
+        if "fsim" in want:
+            fsim()
+        if "vif" in want:
+            m["vif_iter_%d" % i] = float(vif_p(self.fdct, ld, data_range=1))
+        if "nqm" in want:
+            m["nqm_iter_%d" % i] = float(NQM(self.fdct, ld))
+
+    def save_path_load(self, epoch, patient_name, slice_name):
+        self.save_path = os.path.join(self.save_root_path, "Save_Iter_%s" % epoch, patient_name, slice_name)
+        os.makedirs(self.save_path, exist_ok=True)
+
+    def result_data_save(self, data_save=True):
+        os.makedirs(self.save_path, exist_ok=True)
+        if data_save:
+            for ftype, fdata in (("prog_denoise_result", self.progressive_denoise_result),
+                                 ("proj_denoise_result", self.proj_denoise_result),
+                                 ("img_denoise_result", self.img_denoise_result),
+                                 ("proj_denoise_result_2img", self.proj_denoise_convert2img_result)):
+                if len(fdata) > 0:
+                    np.savez_compressed(os.path.join(self.save_path, ftype + ".npz"), **fdata)
+        with open(os.path.join(self.save_path, "metric.json"), "w") as f:
+            f.write(json.dumps(self.metric_instance, sort_keys=False, indent=4, separators=(",", ": ")))
+
+    def metric_total_save(self, epoch):
+        from .denoiser import DotDict
+        self.metric_total = DotDict(aggregate_metrics(self.metric_each_sample))
+        out = os.path.join(self.save_root_path, "Save_Iter_%s" % epoch)
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "metric.json"), "w") as f:
+            f.write(json.dumps(self.metric_total, sort_keys=False, indent=4, separators=(",", ": ")))
+
+    def result_figure_save(self, mode="progressive", display=True, only_metric=False):
+        """The metric half of result_figure_save (:596-763): LDCT against FDCT, then every stored iterate of the
+        mode's result dict, last iterate first.  Figures (matplotlib) are not drawn by this build."""
+        from .denoiser import miu2pixel
+        if mode not in ("progressive", "dimg", "dproj", "dproj2img"):
+            print('ValueError:mode should be one of: "progressive","dimg","dproj","dproj2img"')
+            return -1
+        if not only_metric:
+            raise NotImplementedError("figure rendering is not part of this build: call with only_metric=True")
+        if mode == "dproj":
+            return None
+        store, key = {"progressive": (self.progressive_denoise_result, "deProg"),
+                      "dimg": (self.img_denoise_result, "deImg"),
+                      "dproj2img": (self.proj_denoise_convert2img_result, "deProj2img")}[mode]
+        self.metric_calculate(mode="LDCT", it=0, denoise_result=self.ldct_np)
+        n = len(store)
+        for i in range(1, n + 1):
+            r_it = n + 1 - i
+            self.metric_calculate(mode=key, it=r_it, denoise_result=miu2pixel(store["iter_%d" % r_it][0, 0]))
+        return None
+
+    def init_data_loader(self):
+        o = self.opt
+        if "train" in o.mode:
+            raise NotImplementedError("training is out of scope of this build (DESIGN.md section 7)")
+        self.test_dataset = Siemens_dataset_npz(ldimg_path=o.test_dataset_path_LD_img, fdimg_path=o.test_dataset_path_FD_img,
+                                                ldproj_path=o.test_dataset_path_LD_proj,
+                                                fdproj_path=o.test_dataset_path_FD_proj, proj_clip=o.clip_proj,
+                                                img_clip=o.clip_img, data_type=o.data_type)
+
+    @torch.no_grad()
+    def test(self, epoch):
+        o = self.opt
+        if self.test_dataset is None:
+            self.init_data_loader()
+        if o.test_numbers <= 0:
+            o.test_numbers = len(self.test_dataset)
+        np.random.seed(9527)
+        ids = np.sort(np.random.choice(len(self.test_dataset), o.test_numbers, replace=False))
+        for idx in range(o.test_numbers):
+            ld_img, fd_proj, fd_img, ld_proj = self.test_dataset[ids[idx]]
+            ld_img, fd_img = ld_img[None], fd_img[None]
+            ld_proj = ld_proj[None] if ld_proj is not None else None
+            self.temp_clear()
+            self.metric_clear()
+            self.save_path_load(epoch, self.test_dataset.patient_name[ids[idx]], self.test_dataset.slice_name[ids[idx]])
+            self.data_sample_load(ldct=ld_img, ldproj=ld_proj, fdproj=fd_proj, fdct=fd_img)
+            if o.mode in ("train_proj", "test_proj"):
+                self.proj_denoiser(self.ldproj)
+                self.result_figure_save(mode="dproj2img", display=False, only_metric=not o.display_result)
+            if o.mode in ("train_img", "test_img"):
+                self.img_denoiser(self.ldct, mode="img_only")
+                self.result_figure_save(mode="dimg", display=False, only_metric=not o.display_result)
+            if o.mode == "test_prog":
+                self.progressive_denoiser()
+                self.result_figure_save(mode="progressive", display=False, only_metric=not o.display_result)
+            self.result_data_save(data_save=o.test_result_data_save)
+            self.metric_update()
+        self.metric_total_save(epoch)
+
+    def fit(self):
+        if "test" in self.opt.mode:
+            return self.test(0)
+        raise NotImplementedError("training is out of scope of this build (DESIGN.md section 7)")

@@ -335,6 +335,22 @@ def gen_art_tables():
          theta_n=np.array(st.size))
 
 
+# ------------------------------------------------------------------ 10. NQM (the reference's own metric code)
+def gen_metrics():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_nqm", os.path.join(os.path.dirname(os.path.dirname(M.__file__)),
+                                                                         "Utils", "NQM.py"))
+    nqm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(nqm)
+    out = {}
+    for tag, (n, seed, noise) in {"a": (128, 81, 0.02), "b": (96, 82, 0.08), "c": (512, 83, 0.01)}.items():
+        yy, xx = np.mgrid[0:n, 0:n] / float(n)
+        ref = (0.5 + 0.3 * np.sin(9 * xx) * np.cos(7 * yy) + 0.15 * (((xx - .4) ** 2 + (yy - .6) ** 2) < .04)).astype(np.float32)
+        qry = (ref + noise * synth.hash_normal((n, n), seed)).astype(np.float32)
+        out["nqm_" + tag] = np.array(float(nqm.NQM(ref, qry)))
+    save("metrics", **out)
+
+
 if __name__ == "__main__":
     gen_schedule()
     gen_groups()
@@ -347,3 +363,4 @@ if __name__ == "__main__":
     gen_misc()
     gen_fbp()
     gen_art_tables()
+    gen_metrics()

@@ -654,6 +654,42 @@ def test_drop_in_adaptive_schedule_hand_off():
     assert len(den.progressive_denoise_result) == 4
 
 
+def test_drop_in_dataset_evaluation(tmp_path):
+    """fit() in mode test_prog (Utils/train_test_utils.py:274-322,337-348): dataset trees on disk -> per-slice
+    progressive sample -> metric.json per slice and for the run, result archives."""
+    import json
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG
+    from ipdm_pytorch_amd.unet import UNetModel
+    root = str(tmp_path / "data")
+    for k, sid in enumerate((2, 5)):
+        ell = synth.ellipse_phantom(sid)
+        mu = synth.rasterize(ell).astype(np.float32)
+        sino = synth.fan_sinogram(ell)
+        for kind, arr in (("fdimg", mu), ("ldimg", mu + 0.004 * synth.hash_normal(mu.shape, 900 + sid).astype(np.float32)),
+                          ("ldproj", synth.low_dose(sino, seed=sid))):
+            os.makedirs(os.path.join(root, kind, "L%03d" % sid), exist_ok=True)
+            np.savez(os.path.join(root, kind, "L%03d" % sid, "slice_%03d.npz" % k), arr.astype(np.float32))
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    cfg_load(dict(test_dataset_path_FD_img=root + "/fdimg", test_dataset_path_LD_img=root + "/ldimg",
+                  test_dataset_path_LD_proj=root + "/ldproj", test_numbers=0, metrics=["psnr", "ssim", "nqm"],
+                  test_result_data_save=True, t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=False), opt.__dict__)
+    den = progressive_domain_denoiser(opt, result_save_path=str(tmp_path / "out"), seed=4)
+    den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
+    den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
+    for m, seed in ((den.proj_model, 21), (den.img_model, 22)):
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(m._shapes, seed=seed).items()})
+    den.fit()
+    run = os.path.join(str(tmp_path / "out"), "IPDM_default", "save_test_results", "Save_Iter_0")
+    tot = json.load(open(os.path.join(run, "metric.json")))
+    assert set(tot) >= {"LDCT", "deProg"} and np.isfinite(tot["LDCT"]["psnr_iter_0"]) and "psnr_iter_0_std" in tot["LDCT"]
+    assert tot["LDCT"]["psnr_iter_0"] > 30 and 0 < tot["LDCT"]["ssim_iter_0"] <= 1
+    one = os.path.join(run, "L002", "slice_000")
+    assert os.path.isfile(os.path.join(one, "metric.json")) and os.path.isfile(os.path.join(one, "prog_denoise_result.npz"))
+    assert len(den.metric_each_sample) == 2 and "psnr_iter_1" in den.metric_each_sample[0]["deProg"]
+
+
 # =========================================================================== BASELINE.json's full sizes
 FULL_IMG = dict(in_channels=1, model_channels=64, out_channels=1, attention_resolutions=(8, 16), channel_mult=(1, 1, 2, 2, 4, 4))
 FULL_PROJ = dict(in_channels=1, model_channels=64, out_channels=1, attention_resolutions=(16, 32),
