@@ -207,6 +207,7 @@ def main():
             del den
             torch.cuda.empty_cache()
             os.environ["IPDM_CONV_SPLIT"] = "3"
+            os.environ["IPDM_ATTN_SPLIT"] = "3"
             try:
                 den2 = progressive_domain_denoiser(opt, seed=1234, slice_id0=lo)
                 den2.data_sample_load(ldproj=ldproj)
@@ -219,14 +220,15 @@ def main():
                 d = (out2 - out).float()
                 mse = float((d * d).mean())
                 rng = float(out.max() - out.min())
-                line["alt_modes"] = {"IPDM_CONV_SPLIT=3": {
+                line["alt_modes"] = {"IPDM_CONV_SPLIT=3 IPDM_ATTN_SPLIT=3": {
                     "value": round(n_global / dt, 5), "unit": "slices/s", "ms_per_step": round(dt * 1e3, 2), "steps": 1,
                     "psnr_vs_default_db": round(10 * math.log10(rng * rng / mse), 2) if mse > 0 else None,
-                    "note": "wide 3x3 convs as 3-piece split-bf16 (6 bf16 MFMA terms per product, f32 accumulate); "
+                    "note": "wide 3x3 convs and attention as 3-piece split-bf16 (6 bf16 MFMA terms per product, f32 accumulate); "
                             "passes the same parity tests at the same tolerances; not the headline"}}
                 del den2
             finally:
                 del os.environ["IPDM_CONV_SPLIT"]
+                del os.environ["IPDM_ATTN_SPLIT"]
         if not args.no_cpu_baseline and world == 1:
             tb, used, cores = cpu_baseline()
             per_slice = n_fwd_proj * tb["proj"] + n_fwd_img * tb["img"] + tb["fbp"]

@@ -224,6 +224,9 @@ int ipdm_bench_attention(int32_t B, int32_t heads, int32_t d, int32_t T, int32_t
  * weights are packed): 0 = plain layout (direct / legacy kernels), 2 | 4 = conv_ws cout-interleaved f32 MFMA,
  * 102 | 103 = opt-in split-bf16 (IPDM_CONV_SPLIT=2|3).  Test aid: lets a parity test prove which path it ran. */
 int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
+/* Which attention kernel a launch with head dim d takes NOW: 0 = 4-wave kernel (d = 32, or IPDM_ATTN_LEGACY),
+ * 1 = wave-specialised exact-f32 MFMA (the default for d = 64), 3 = opt-in split-bf16 (IPDM_ATTN_SPLIT=3). */
+int32_t ipdm_attention_kernel_code(int32_t d);
 
 #ifdef __cplusplus
 }

@@ -336,7 +336,9 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
 
 namespace ipdm {
 
-int attention_launch(const float *qkv, float *out, int B, int heads, int d, int T, hipStream_t st)
+size_t attention_scratch_floats(int B, int heads, int d, int T) { return d == 64 ? attention_sx_scratch_floats(B, heads, T) : 0; }
+
+int attention_launch(const float *qkv, float *out, int B, int heads, int d, int T, hipStream_t st, float *scratch)
 {
     IPDM_REQUIRE(qkv && out && B > 0 && heads > 0 && T > 0, "attention: bad argument");
     if (d != 64 && d != 32) { set_error("attention: head dim %d unsupported (kernel is specialised for 64 and 32)", d); return IPDM_ERR_UNSUPPORTED; }
@@ -345,7 +347,11 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
     const bool prof = prof_enabled();
     if (prof) prof_before(2, st);
     static const bool legacy = getenv("IPDM_ATTN_LEGACY") != nullptr;
-    if (d == 64 && !legacy) {
+    const char *split_env = getenv("IPDM_ATTN_SPLIT");      // read per launch: one process may run both modes
+    if (d == 64 && split_env && atoi(split_env) == 3) {
+        const int rc = attention_sx_launch(qkv, scratch, out, B, heads, T, scale, st);
+        if (rc) return rc;
+    } else if (d == 64 && !legacy) {
         // wave-specialised kernel, one 512-thread workgroup per CU.  64 queries per consumer wave (K/V operand reads
         // shared by two query tiles) when the 256-query workgroups come in whole rounds of the CUs, else 32
         constexpr size_t lds = (size_t)2 * (KV * KP + 64 * VP) * sizeof(float);
@@ -378,8 +384,25 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
 
 }  // namespace ipdm
 
+extern "C" int32_t ipdm_attention_kernel_code(int32_t d)
+{
+    const char *split_env = getenv("IPDM_ATTN_SPLIT");
+    if (d == 64 && split_env && atoi(split_env) == 3) return 3;
+    return (d == 64 && getenv("IPDM_ATTN_LEGACY") == nullptr) ? 1 : 0;
+}
+
 extern "C" int ipdm_op_attention(const float *d_qkv, float *d_out, int32_t B, int32_t heads, int32_t d, int32_t T,
                                  void *stream)
 {
-    return ipdm::attention_launch(d_qkv, d_out, B, heads, d, T, (hipStream_t)stream);
+    // test helper: allocates the split mode's scratch itself (the UNet executor takes it from its workspace)
+    float *scratch = nullptr;
+    if (ipdm_attention_kernel_code(d) == 3) {
+        IPDM_HIP_CHECK(hipMalloc((void **)&scratch, ipdm::attention_scratch_floats(B, heads, d, T) * sizeof(float)));
+    }
+    const int rc = ipdm::attention_launch(d_qkv, d_out, B, heads, d, T, (hipStream_t)stream, scratch);
+    if (scratch) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(scratch);
+    }
+    return rc;
 }

@@ -615,7 +615,13 @@ struct Fwd {
         gn(x, nullptr, ap.n);
         Tensor *qkv = conv(x, nullptr, ap.qkv, 1, 1, nullptr, nullptr, H, W);
         Tensor *a = make(x->C, H, W);
-        if (!rc && !net->dry) rc = attention_launch(ptr(qkv), wptr(a), net->B, net->cfg.num_heads, x->C / net->cfg.num_heads, H * W, net->st);
+        // scratch of the opt-in split-bf16 attention (pre-split K/V tile images); carved in every mode so that the
+        // workspace walk does not depend on the environment
+        const int heads = net->cfg.num_heads, hd = x->C / heads;
+        const size_t sfl = attention_scratch_floats(net->B, heads, hd, H * W);
+        Tensor *scr = sfl ? make((int)((sfl + (size_t)net->B * H * W - 1) / ((size_t)net->B * H * W)), H, W) : nullptr;
+        if (!rc && !net->dry) rc = attention_launch(ptr(qkv), wptr(a), net->B, heads, hd, H * W, net->st, scr ? wptr(scr) : nullptr);
+        if (scr) release(scr);
         release(qkv);
         Tensor *o = conv(a, nullptr, ap.proj, 1, 0, ap.proj.b, x, H, W);
         release(a);
@@ -887,17 +893,19 @@ extern "C" int ipdm_bench_attention(int32_t B, int32_t heads, int32_t d, int32_t
     IPDM_HIP_CHECK(hipMalloc((void **)&d_out, (size_t)B * heads * d * T * 4));
     ipdm_randn(d_qkv, B, (int64_t)heads * 3 * d * T, 9, 0, 0, nullptr);
     int rc = 0;
-    for (int i = 0; i < 2 && !rc; ++i) rc = attention_launch(d_qkv, d_out, B, heads, d, T, nullptr);
+    float *d_scr = nullptr;
+    if (attention_scratch_floats(B, heads, d, T)) IPDM_HIP_CHECK(hipMalloc((void **)&d_scr, attention_scratch_floats(B, heads, d, T) * 4));
+    for (int i = 0; i < 2 && !rc; ++i) rc = attention_launch(d_qkv, d_out, B, heads, d, T, nullptr, d_scr);
     hipEvent_t e0, e1;
     IPDM_HIP_CHECK(hipEventCreate(&e0));
     IPDM_HIP_CHECK(hipEventCreate(&e1));
     IPDM_HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters && !rc; ++i) rc = attention_launch(d_qkv, d_out, B, heads, d, T, nullptr);
+    for (int i = 0; i < iters && !rc; ++i) rc = attention_launch(d_qkv, d_out, B, heads, d, T, nullptr, d_scr);
     IPDM_HIP_CHECK(hipEventRecord(e1, nullptr));
     IPDM_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;
     IPDM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = ms / iters;
-    (void)hipFree(d_qkv); (void)hipFree(d_out); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(d_qkv); (void)hipFree(d_out); (void)hipFree(d_scr); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
 }

@@ -65,7 +65,12 @@ constexpr int GN_SPLIT = 64;
 size_t gn_partials_bytes(int B, int groups);
 int gn_stats_launch(const GnArgs &a, hipStream_t st);
 
-int attention_launch(const float *qkv, float *out, int B, int heads, int d, int T, hipStream_t st);
+// scratch: attention_scratch_floats() floats, used only by the opt-in split-bf16 variant (may be null otherwise)
+int attention_launch(const float *qkv, float *out, int B, int heads, int d, int T, hipStream_t st, float *scratch = nullptr);
+size_t attention_scratch_floats(int B, int heads, int d, int T);
+// opt-in split-bf16 variant (attn_sx.hip, IPDM_ATTN_SPLIT=3), d = 64 only
+size_t attention_sx_scratch_floats(int B, int heads, int T);
+int attention_sx_launch(const float *qkv, float *scratch, float *out, int B, int heads, int T, float scale, hipStream_t st);
 
 // time embedding: emb = Linear(SiLU(Linear(sinusoid(t)))) ; out = SiLU(emb)  (Model/model.py:14-32,218-222,105-108)
 int temb_launch(const float *freqs, int mc, int t, const float *w0, const float *b0, const float *w2, const float *b2,

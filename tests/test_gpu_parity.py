@@ -344,6 +344,18 @@ def test_attention_kernel(B, heads, T):
     assert (out.cpu() - want).abs().max() <= 2e-5
 
 
+@pytest.mark.parametrize("B,heads,T", [(1, 4, 117), (2, 4, 1024), (1, 4, 1827), (1, 2, 4096)])
+def test_attention_kernel_split_bf16_x6(B, heads, T, monkeypatch):
+    """IPDM_ATTN_SPLIT=3: both contractions as 3-piece split-bf16 (6 MFMA terms, f32 accumulate) at the SAME tolerance
+    as the exact-f32 kernel (ragged key blocks, several tiles, the rescale branch)."""
+    from ipdm_pytorch_amd import _lib
+    monkeypatch.delenv("IPDM_ATTN_SPLIT", raising=False)
+    assert _lib.lib().ipdm_attention_kernel_code(64) == 1
+    monkeypatch.setenv("IPDM_ATTN_SPLIT", "3")
+    assert _lib.lib().ipdm_attention_kernel_code(64) == 3       # the split kernel is what runs
+    test_attention_kernel(B, heads, T)
+
+
 def test_attention_random_lengths():
     """Seeded random (B, heads, T): every ragged-tail length class of the 64-key tiles and 128/256-query workgroups."""
     from ipdm_pytorch_amd import _lib
