@@ -71,10 +71,14 @@ __device__ inline SxTile sx_decode(const ConvArgs &a, int tile)
     return t;
 }
 
-// WM: 32-cout blocks per tile (4 or 2); WR = 4 / WM row groups of 8 rows; NS: pieces per operand (3 or 2)
-template <int WM, int NS>
-__global__ void __launch_bounds__(512) conv_sx_kernel(ConvArgs a, int ntiles)
+// WM: 32-cout blocks per tile (4 or 2); WR = 4 / WM row groups of 8 rows; NS: pieces per operand (3 or 2);
+// CW: consumer waves per SIMD (1: four waves of 8 accumulators; 2: eight waves of 4 -- the bf16 matrix pipe takes
+// another wave's MFMAs while one waits for its operands, which a single wave per SIMD cannot hide)
+template <int WM, int NS, int CW>
+__global__ void __launch_bounds__(256 * CW + 256) conv_sx_kernel(ConvArgs a, int ntiles)
 {
+    constexpr int NCT = 256 * CW;           // consumer threads
+    constexpr int NQ = 8 / CW;              // rows (accumulators) per consumer wave
     constexpr int WR = 4 / WM, TH = 8 * WR, BN = 32 * WM;
     constexpr int IN_ROWS = TH + 2, IN_COLS = 34, NPIX = IN_ROWS * IN_COLS;
     constexpr int SP = (NPIX + 255) / 256;
@@ -92,9 +96,9 @@ __global__ void __launch_bounds__(512) conv_sx_kernel(ConvArgs a, int ntiles)
     const int S = n_my * nchunks;
     const int plane_bytes = a.Hs * a.Ws * 4;
 
-    if (threadIdx.x >= 256) {
+    if (threadIdx.x >= NCT) {
         // =========================================================================== PRODUCERS
-        const int tid = threadIdx.x - 256;
+        const int tid = threadIdx.x - NCT;
         int in_voff[SP];
         bool in_ok[SP];
         SxTile t = {0, 0, 0, 0};
@@ -180,9 +184,10 @@ __global__ void __launch_bounds__(512) conv_sx_kernel(ConvArgs a, int ntiles)
     // =============================================================================== CONSUMERS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lk = lane >> 5, l31 = lane & 31;
-    const int wm = wave % WM, wr = wave / WM;          // this wave's cout block and row group
-    const int swm = __builtin_amdgcn_readfirstlane(wm), swr = __builtin_amdgcn_readfirstlane(wr);
-    f32x16 acc[8];
+    const int wm = (wave & 3) % WM, wr = (wave & 3) / WM;      // this wave's cout block and row group
+    const int swm = __builtin_amdgcn_readfirstlane(wm);
+    const int row0 = __builtin_amdgcn_readfirstlane(wr * 8 + (wave >> 2) * NQ);     // first of this wave's NQ rows
+    f32x16 acc[NQ];
     const int out_plane = a.Ho * a.Wo;
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
     // packed weights: [cout block][chunk][tap][piece][lane 64][8 bf16] = 1 KB per (block, chunk, tap, piece)
@@ -194,7 +199,7 @@ __global__ void __launch_bounds__(512) conv_sx_kernel(ConvArgs a, int ntiles)
         const SxTile t = sx_decode<TH, BN>(a, tile_of(k));
         if (ch == 0) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
         }
@@ -216,8 +221,8 @@ __global__ void __launch_bounds__(512) conv_sx_kernel(ConvArgs a, int ntiles)
                 for (int p = 0; p < NS; ++p) an[p] = wp[((tap + 1) * NS + p) * 64];
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int pix = (swr * 8 + q + ky) * IN_COLS + l31 + kx;
+            for (int q = 0; q < NQ; ++q) {
+                const int pix = (row0 + q + ky) * IN_COLS + l31 + kx;
                 u32x4 b[NS];
 #pragma unroll
                 for (int p = 0; p < NS; ++p)
@@ -234,7 +239,7 @@ __global__ void __launch_bounds__(512) conv_sx_kernel(ConvArgs a, int ntiles)
             // + bias (one f32 MFMA per accumulator: A = bias of the lane's cout on the k=0 half, B = 1), then the epilogue
             const float bv = bload(b_rsrc, lk ? SX_OOB : l31 * 4, min(t.co0 + swm * 32, a.Cout - 1) * 4);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, 1.0f, acc[q], 0, 0, 0);
+            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, 1.0f, acc[q], 0, 0, 0);
             const size_t sample = (size_t)t.n * a.Cout * out_plane;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * out_plane * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0, a.Cout * out_plane * 4, 0x00020000);
@@ -249,8 +254,8 @@ __global__ void __launch_bounds__(512) conv_sx_kernel(ConvArgs a, int ntiles)
                     const bool odd = (l31 & 1) != 0, hi = (l31 & 2) != 0;
 #define SX_XCHG(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int oy = t.oy0 + swr * 8 + q;
+                    for (int q = 0; q < NQ; ++q) {
+                        const int oy = t.oy0 + row0 + q;
                         const int voff = (xok && oy < a.Ho) ? lane_off4 : SX_OOB;
                         const int so = cob * plane4 + (min(oy, a.Ho - 1) * a.Wo + t.ox0) * 4;
                         f32x4 rv[4];
@@ -279,8 +284,8 @@ __global__ void __launch_bounds__(512) conv_sx_kernel(ConvArgs a, int ntiles)
                 } else {
                     const int lane_off = (lk * 4 * out_plane + l31) * 4;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int oy = t.oy0 + swr * 8 + q;
+                    for (int q = 0; q < NQ; ++q) {
+                        const int oy = t.oy0 + row0 + q;
                         const int voff = (t.ox0 + l31 < a.Wo && oy < a.Ho) ? lane_off : SX_OOB;
                         int so = cob * plane4 + (min(oy, a.Ho - 1) * a.Wo + t.ox0) * 4;
 #pragma unroll
@@ -311,7 +316,7 @@ int sx_num_cus()
     return n;
 }
 
-template <int WM, int NS>
+template <int WM, int NS, int CW>
 int launch_sx(const ConvArgs &args, hipStream_t st)
 {
     constexpr int WR = 4 / WM, TH = 8 * WR, BN = 32 * WM;
@@ -332,12 +337,12 @@ int launch_sx(const ConvArgs &args, hipStream_t st)
     G = (G + 7) / 8 * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_sx_kernel<WM, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_sx_kernel<WM, NS, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const bool prof = prof_enabled();
     if (prof) prof_before(0, st);
-    hipLaunchKernelGGL((conv_sx_kernel<WM, NS>), dim3((unsigned)G), dim3(512), lds, st, a, (int)ntiles);
+    hipLaunchKernelGGL((conv_sx_kernel<WM, NS, CW>), dim3((unsigned)G), dim3(256 * CW + 256), lds, st, a, (int)ntiles);
     if (prof) prof_after(0, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * 9, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
@@ -388,8 +393,16 @@ int conv2d_sx_launch(const ConvArgs &a, hipStream_t st)
     const int ns = conv_sx_pieces(a.w_interleave);
     IPDM_REQUIRE(a.ksize == 3 && a.stride == 1 && (ns == 2 || ns == 3), "conv2d(split): unsupported configuration");
     const bool wide = a.Cout > 96;
-    if (ns == 3) return wide ? launch_sx<4, 3>(a, st) : launch_sx<2, 3>(a, st);
-    return wide ? launch_sx<4, 2>(a, st) : launch_sx<2, 2>(a, st);
+    // A/B switch: two consumer waves per SIMD (eight waves of 4 accumulators).  Measured equal to one (226 vs 228
+    // TFLOP/s-equivalent on 128->128 @512^2): at 66 % matrix-pipe occupancy and 1.7 GHz the kernel sits at 86 % of the
+    // 1585 TFLOP/s the chip sustains on a pure bf16 MFMA stream -- the limit is the power-managed clock, not issue bubbles.
+    static const bool cw2 = getenv("IPDM_CONV_SX_CW2") != nullptr;
+    if (cw2) {
+        if (ns == 3) return wide ? launch_sx<4, 3, 2>(a, st) : launch_sx<2, 3, 2>(a, st);
+        return wide ? launch_sx<4, 2, 2>(a, st) : launch_sx<2, 2, 2>(a, st);
+    }
+    if (ns == 3) return wide ? launch_sx<4, 3, 1>(a, st) : launch_sx<2, 3, 1>(a, st);
+    return wide ? launch_sx<4, 2, 1>(a, st) : launch_sx<2, 2, 1>(a, st);
 }
 
 }  // namespace ipdm
