@@ -18,6 +18,7 @@ from .config import cfg_load
 from .diffusion import GaussianDiffusion, NoiseSource
 from .fbp import FBP, tensor_sharpen
 from .evaluate import EvaluationMixin
+from .normalize import yeo_johnson_transform
 from .unet import UNetModel
 
 
@@ -76,6 +77,7 @@ class progressive_domain_denoiser(EvaluationMixin):
         self.img_denoise_result = ResultTempDict()
         self.progressive_denoise_result = ResultTempDict()
         self.noise_strength = None
+        self.trans_ldproj = self.trans_ldimg = None     # fitted power transforms of the loaded sample (opt.normal)
         self.noise = None          # optional NoiseSource / InjectedNoise override (parity tests)
         # metric bookkeeping and the result tree <result_save_path>/<model>_<run>/save_test_results (:131-133,156-200);
         # without a result_save_path nothing is created until test() / save_path_load() is asked for
@@ -171,13 +173,19 @@ class progressive_domain_denoiser(EvaluationMixin):
 
     # ------------------------------------------------------------------ data (:569-594)
     def data_sample_load(self, ldct=None, ldproj=None, fdproj=None, fdct=None):
-        if self.opt.normal:
-            raise NotImplementedError("opt.normal (Yeo-Johnson) is off in every shipped config")
         if ldct is not None:
-            self.ldct = ldct.to(self.opt.device)
+            if self.opt.normal:        # :578-580
+                ldct_norm, self.trans_ldimg = yeo_johnson_transform(ldct)
+                self.ldct = ldct_norm.to(self.opt.device)
+            else:
+                self.ldct = ldct.to(self.opt.device)
             self.ldct_np = miu2pixel(ldct.squeeze().cpu().numpy())
         if ldproj is not None:
-            self.ldproj = ldproj.to(self.opt.device)
+            if self.opt.normal:        # :585-587
+                ldproj_norm, self.trans_ldproj = yeo_johnson_transform(ldproj)
+                self.ldproj = ldproj_norm.to(self.opt.device)
+            else:
+                self.ldproj = ldproj.to(self.opt.device)
             self.ldproj_np = ldproj.squeeze().cpu().numpy()
         if fdct is not None:
             self.fdct = miu2pixel(fdct).squeeze().numpy()
@@ -207,7 +215,7 @@ class progressive_domain_denoiser(EvaluationMixin):
             model=self.proj_model, img=x.to(self.proj_device, torch.float32), t_start=o.t_start_proj, clip=o.clip_proj,
             lambda_ratio=o.lambda_ratio_proj, eta=o.eta_proj, mode="proj", constant_guidance=o.constant_guidance_proj,
             kernel_size_proj=o.kernel_size_proj, amplitude_proj=o.amplitude_proj, only_convertor=o.benchmark_test,
-            normal=o.normal, noise=self._noise(), rank_max=self._rank_max())
+            normal=o.normal, transformer=self.trans_ldproj, noise=self._noise(), rank_max=self._rank_max())
 
     def _rank_max(self):
         """Adaptive pass schedule (t_start_proj=None) under slice sharding: the branch is taken on the maximum over
@@ -226,7 +234,7 @@ class progressive_domain_denoiser(EvaluationMixin):
         common = dict(model=self.img_model, clip=o.clip_img, lambda_ratio=o.lambda_ratio_img,
                       save_states=o.save_states_img, noise_strength=noise_strength, ldct=xd, mode="img",
                       kernel_size_img=o.kernel_size_img, amplitude_img=o.amplitude_img,
-                      only_convertor=o.benchmark_test, normal=o.normal, noise=self._noise())
+                      only_convertor=o.benchmark_test, normal=o.normal, transformer=self.trans_ldimg, noise=self._noise())
         if o.sample_method_img == "sparse":        # Utils/train_test_utils.py:505-514
             result = self.img_gaussian_diffusion.sparse_guided_reverse_process(
                 model=self.img_model, condition=xd, t_start=o.t_start_img, condition_lambda_max=0.5, condition_lambda_min=0.3,
@@ -282,6 +290,8 @@ class progressive_domain_denoiser(EvaluationMixin):
         if not (self.opt.convertor == "FBP" and self.opt.fbp_sharpen):
             sharpen_num = -1
         x = tensor_sharpen(result.to(self.opt.device), sharpen_num)
+        if self.opt.normal:         # :560-562
+            x, self.trans_ldimg = yeo_johnson_transform(x)
         return self.img_denoiser(x, noise_strength=n_s, save_state=self.opt.save_it_state_img)
 
     # ------------------------------------------------------------------ fast path (no host copies)
@@ -295,6 +305,8 @@ class progressive_domain_denoiser(EvaluationMixin):
         img = self._convert_dev(result[-1], 10 if self.opt.clip_proj else 1)
         if self.opt.convertor == "FBP" and self.opt.fbp_sharpen:
             img = tensor_sharpen(img, sharpen_num)
+        if self.opt.normal:
+            img, self.trans_ldimg = yeo_johnson_transform(img)
         return self._img_dense(img, n_s, self.opt.ultra_img_denoise)[-1]
 
 

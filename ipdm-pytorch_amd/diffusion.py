@@ -159,8 +159,7 @@ class GaussianDiffusion:
         noise_strength).  Extra keyword: `noise` = NoiseSource / InjectedNoise (default: NoiseSource(0))."""
         if kwargs.get("only_convertor"):
             return [img], None, None
-        if kwargs.get("normal"):
-            raise NotImplementedError("opt.normal (Yeo-Johnson) is off in every shipped config (SURVEY.md section 2)")
+        normal = bool(kwargs.get("normal"))        # iterates are reported through the inverse power transform (:616-617)
         noise = noise if noise is not None else NoiseSource(0)
         img = img.to(torch.float32).contiguous()
         B = img.shape[0]
@@ -219,7 +218,11 @@ class GaussianDiffusion:
                             t_list, noise_strength, eta = [20, 18, 15], "mid", 0.5
                         else:
                             t_list, noise_strength, eta = [15, 15, 15], "low", 0.5
-            iters_out.append(x)
+            if normal:
+                from .normalize import yeo_johnson_inverse_transform
+                iters_out.append(yeo_johnson_inverse_transform(x.contiguous(), kwargs["transformer"]).to(torch.float32))
+            else:
+                iters_out.append(x)
             if constant_guidance is None:
                 if it >= 1:
                     guide = self._guide_update(mode, eta, x, img, ldct)

@@ -125,3 +125,19 @@ def test_result_writers_and_metric_calculate(tmp_path):
         raise AssertionError("fsim should be refused")
     except NotImplementedError:
         pass
+
+
+def test_yeo_johnson_round_trip_and_per_slice():
+    """opt.normal helpers (Model/model.py:762-808): sklearn's standardised Yeo-Johnson transform, one per slice."""
+    from sklearn.preprocessing import PowerTransformer
+    from ipdm_pytorch_amd.normalize import yeo_johnson_transform, yeo_johnson_inverse_transform
+    x = torch.from_numpy((synth.hash_uniform((2, 1, 24, 20), 77) ** 2 * 3).astype(np.float32))
+    y, trs = yeo_johnson_transform(x)
+    assert tuple(y.shape) == tuple(x.shape) and len(trs) == 2
+    for b in range(2):                                   # a batch of B equals B single calls, and equals bare sklearn
+        want = PowerTransformer(method="yeo-johnson").fit_transform(x[b].numpy().reshape(-1, 1)).reshape(1, 24, 20)
+        assert np.array_equal(y[b].numpy(), want)
+        assert abs(float(y[b].mean())) < 1e-6 and abs(float(y[b].std(unbiased=False)) - 1) < 1e-6
+    back = yeo_johnson_inverse_transform(y, trs)
+    assert np.abs(back.numpy() - x.numpy()).max() < 1e-5
+    assert np.array_equal(yeo_johnson_inverse_transform(y[:1], trs[0]).numpy(), back[:1].numpy())     # bare transformer form

@@ -666,6 +666,48 @@ def test_drop_in_adaptive_schedule_hand_off():
     assert len(den.progressive_denoise_result) == 4
 
 
+def test_normal_mode_reports_inverse_transformed_iterates():
+    """opt.normal (Model/model.py:616-617): the loop runs on the transformed tensor and every reported iterate (and
+    their final average) goes through the inverse power transform; nothing else changes."""
+    from ipdm_pytorch_amd.diffusion import GaussianDiffusion, NoiseSource
+    from ipdm_pytorch_amd.normalize import yeo_johnson_transform, yeo_johnson_inverse_transform
+    net, _ = _native_unet(LOOP_CFG, 41)
+    gd = GaussianDiffusion(1000, "cosine", 5)
+    raw = torch.from_numpy(synth.hash_uniform((2, 1, 40, 24), 43)) * 0.6
+    x, trs = yeo_johnson_transform(raw)
+    x = x.to(torch.float32).to(DEV)
+    kw = dict(model=net, img=x, mode="proj", t_start=[3, 2], clip=False, lambda_ratio=1, eta=0.5, constant_guidance=None,
+              lambda_curve=None, kernel_size_proj=4, amplitude_proj=7, only_convertor=False, noise_strength=None)
+    plain, _, _ = gd.guided_reverse_process(normal=False, noise=NoiseSource(7, 0), **kw)
+    norm, _, _ = gd.guided_reverse_process(normal=True, transformer=trs, noise=NoiseSource(7, 0), **kw)
+    assert len(norm) == len(plain) == 3
+    for k in range(2):
+        want = yeo_johnson_inverse_transform(plain[k], trs).to(torch.float32)
+        assert torch.equal(norm[k], want)
+    assert torch.allclose(norm[2], (norm[0] + norm[1]) / 2, atol=1e-6)          # the average of the REPORTED iterates
+
+
+def test_drop_in_normal_option():
+    """update_opt(normal=True) end to end on the reduced nets: data_sample_load transforms, both loops report through the
+    inverse transforms (Utils/train_test_utils.py:560-562,578-588)."""
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG
+    from ipdm_pytorch_amd.unet import UNetModel
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    den = progressive_domain_denoiser(opt, seed=6)
+    den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
+    den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
+    for m, seed in ((den.proj_model, 21), (den.img_model, 22)):
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(m._shapes, seed=seed).items()})
+    den.update_opt(dict(normal=True, t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=False))
+    sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(2)), seed=2)
+    den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
+    assert den.trans_ldproj is not None and abs(float(den.ldproj.mean())) < 1e-3       # standardised input
+    out = den.progressive_denoiser(sharpen_num=70)
+    assert tuple(out.shape) == (1, 1, 512, 512) and bool(torch.isfinite(out).all()) and den.trans_ldimg is not None
+
+
 def test_drop_in_dataset_evaluation(tmp_path):
     """fit() in mode test_prog (Utils/train_test_utils.py:274-322,337-348): dataset trees on disk -> per-slice
     progressive sample -> metric.json per slice and for the run, result archives."""
