@@ -4,8 +4,9 @@ proj_denoiser / img_denoiser / progressive_denoiser and the result dictionaries.
 
 Everything between data_sample_load and the returned tensor stays on the GPU; slices of a batch are
 independent (per-slice semantics) and may be sharded over ranks (`world=` keyword, see dist.py).
-Training, dataset iteration, figure/metric dumps and the ART convertor are out of scope
- and raise NotImplementedError when asked for.
+The SURVEY 8(f) rows are mixed in from their own modules: the ART convertor (art.py), dataset iteration / metric and
+result files / test() / fit() (evaluate.py), opt.normal (normalize.py).  Training and figure rendering are out of scope
+and raise NotImplementedError when asked for.
 """
 import copy
 import os
