@@ -6,8 +6,9 @@
 Metrics: the reference calls scikit-image 0.19.3 (psnr, ssim), piq 0.8.0 (vif_p, fsim) and its own Utils/NQM.py.  None of
 the two packages exists in this image, so psnr / ssim / vif_p restate the published algorithms with those versions'
 defaults (the call sites fix win_size=11, data_range=1, chromatic=False); nqm restates Utils/NQM.py and is pinned on
-values computed by the reference's own function (tests/golden/metrics.npz).  fsim (phase congruency over a log-Gabor
-bank with a dozen library-specific constants) is not restated: asking for it raises NotImplementedError.
+values computed by the reference's own function (tests/golden/metrics.npz).  fsim restates Zhang et al.'s index with
+Kovesi's phase congruency in the parameterisation piq 0.8.0 documents -- like psnr / ssim / vif_p it is checked against
+its definition, not against the absent package.
 """
 import glob
 import json
@@ -129,8 +130,86 @@ def NQM(image_origin, image_query, view_angle=1):
     return 10 * np.log10(np.sum(y1 ** 2) / np.sum((y1 - y2) ** 2))
 
 
-def fsim(*_a, **_k):
-    raise NotImplementedError("fsim (piq 0.8.0) is not restated in this build: drop 'fsim' from opt.metrics")
+def _freq_grid(h, w):
+    """Normalised frequency coordinates in [-0.5, 0.5), rows x cols ('ij')."""
+    def axis(n):
+        return np.arange(-(n - 1) / 2, n / 2) / (n - 1) if n % 2 else np.arange(-n / 2, n / 2) / n
+    return np.meshgrid(axis(h), axis(w), indexing="ij")
+
+
+def _phase_congruency(x, scales=4, orientations=4, min_length=6, mult=2, sigma_f=0.55, delta_theta=1.2, k=2.0):
+    """Kovesi's phase congruency (the PC_2 measure with his noise compensation) over a bank of `scales` x `orientations`
+    log-Gabor filters, as FSIM uses it: per orientation the energy  sum_s (e_s cos(phi) + o_s sin(phi) - |e_s sin(phi) -
+    o_s cos(phi)|)  against the mean phase phi, minus a noise threshold estimated from the median response at the finest
+    scale, summed over orientations and divided by the summed amplitudes."""
+    h, w = x.shape
+    eps = np.finfo(x.dtype).eps
+    gx, gy = _freq_grid(h, w)
+    radius = np.fft.ifftshift(np.sqrt(gx ** 2 + gy ** 2))
+    theta = np.fft.ifftshift(np.arctan2(-gy, gx))
+    radius[0, 0] = 1
+    lowpass = np.fft.ifftshift(1.0 / (1.0 + (np.sqrt(gx ** 2 + gy ** 2) / 0.45) ** (2 * 15)))
+    radial = []
+    for s in range(scales):
+        f0 = 1.0 / (min_length * mult ** s)
+        g = np.exp(-(np.log(radius / f0) ** 2) / (2 * np.log(sigma_f) ** 2)) * lowpass
+        g[0, 0] = 0
+        radial.append(g)
+    theta_sigma = np.pi / (orientations * delta_theta)
+    fx = np.fft.fft2(x)
+    energy_all = np.zeros((h, w), x.dtype)
+    an_all = np.zeros((h, w), x.dtype)
+    for o in range(orientations):
+        ang = o * np.pi / orientations
+        ds = np.sin(theta) * np.cos(ang) - np.cos(theta) * np.sin(ang)
+        dc = np.cos(theta) * np.cos(ang) + np.sin(theta) * np.sin(ang)
+        spread = np.exp(-(np.abs(np.arctan2(ds, dc)) ** 2) / (2 * theta_sigma ** 2))
+        filt = [spread * g for g in radial]
+        eo = [np.fft.ifft2(fx * f) for f in filt]
+        an = sum(np.abs(e) for e in eo)
+        sum_e, sum_o = sum(e.real for e in eo), sum(e.imag for e in eo)
+        xen = np.sqrt(sum_e ** 2 + sum_o ** 2) + eps
+        me, mo = sum_e / xen, sum_o / xen
+        energy = sum(e.real * me + e.imag * mo - np.abs(e.real * mo - e.imag * me) for e in eo)
+        # noise threshold from the finest scale (Rayleigh model of the noise energy)
+        noise_power = (-np.median(np.abs(eo[0]) ** 2) / np.log(0.5)) / np.sum(filt[0] ** 2)
+        fi = [np.fft.ifft2(f).real * np.sqrt(h * w) for f in filt]
+        sum_an2 = sum(np.sum(f ** 2) for f in fi)
+        sum_aiaj = sum(np.sum(fi[a] * fi[b]) for a in range(scales - 1) for b in range(a + 1, scales))
+        tau = np.sqrt((2 * noise_power * sum_an2 + 4 * noise_power * sum_aiaj) / 2)
+        t = (tau * np.sqrt(np.pi / 2) + k * np.sqrt((2 - np.pi / 2) * tau ** 2)) / 1.7
+        energy_all += np.maximum(energy - t, 0)
+        an_all += an
+    return (energy_all + eps) / (an_all + eps)
+
+
+def fsim(x, y, data_range=1.0, chromatic=False):
+    """Feature Similarity Index (Zhang et al. 2011), luminance form (the call site passes chromatic=False): images on a
+    0..255 scale, averaged down to ~256 pixels on the short side, phase-congruency similarity (T1 = 0.85) x Scharr
+    gradient-magnitude similarity (T2 = 160), pooled with weights max(PC_x, PC_y).  Restated from the paper and from
+    the layout of piq 0.8.0's implementation (package absent here: unpinned)."""
+    if chromatic:
+        raise NotImplementedError("fsim: only the luminance form used by the sampling harness is built")
+    a = np.asarray(x, dtype=np.float32).reshape(np.shape(x)[-2:]) / float(data_range) * 255
+    b = np.asarray(y, dtype=np.float32).reshape(np.shape(y)[-2:]) / float(data_range) * 255
+    ks = max(1, round(min(a.shape) / 256))
+    if ks > 1:
+        hh, ww = a.shape[0] // ks * ks, a.shape[1] // ks * ks
+        a = a[:hh, :ww].reshape(hh // ks, ks, ww // ks, ks).mean(axis=(1, 3))
+        b = b[:hh, :ww].reshape(hh // ks, ks, ww // ks, ks).mean(axis=(1, 3))
+    pc_a, pc_b = _phase_congruency(a), _phase_congruency(b)
+    scharr = np.array([[-3., 0., 3.], [-10., 0., 10.], [-3., 0., 3.]], dtype=np.float32) / 16
+
+    def grad(img):
+        gxx = ndimage.correlate(img, scharr, mode="constant")
+        gyy = ndimage.correlate(img, scharr.T, mode="constant")
+        return np.sqrt(gxx ** 2 + gyy ** 2)
+
+    ga, gb = grad(a), grad(b)
+    s_pc = (2 * pc_a * pc_b + 0.85) / (pc_a ** 2 + pc_b ** 2 + 0.85)
+    s_g = (2 * ga * gb + 160) / (ga ** 2 + gb ** 2 + 160)
+    pc_max = np.maximum(pc_a, pc_b)
+    return float(np.sum(s_g * s_pc * pc_max) / np.sum(pc_max))
 
 
 # ----------------------------------------------------------------------------------------------- metric bookkeeping
@@ -258,7 +337,7 @@ class EvaluationMixin:
         if "ssim" in want:
             m["ssim_iter_%d" % i] = float(compare_ssim(self.fdct, ld, win_size=11, data_range=1))
         if "fsim" in want:
-            fsim()
+            m["fsim_iter_%d" % i] = float(fsim(self.fdct, ld, data_range=1, chromatic=False))
         if "vif" in want:
             m["vif_iter_%d" % i] = float(vif_p(self.fdct, ld, data_range=1))
         if "nqm" in want:

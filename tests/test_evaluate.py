@@ -120,11 +120,20 @@ def test_result_writers_and_metric_calculate(tmp_path):
     tot = json.load(open(os.path.join(den.save_root_path, "Save_Iter_0", "metric.json")))
     assert tot["LDCT"]["psnr_iter_0_std"] == 0.0 and abs(tot["LDCT"]["psnr_iter_0"] - m["LDCT"]["psnr_iter_0"]) < 1e-12
     den.opt.metrics = ["fsim"]
-    try:
-        den.metric_calculate(mode="LDCT", it=0, denoise_result=qry.copy())
-        raise AssertionError("fsim should be refused")
-    except NotImplementedError:
-        pass
+    den.metric_calculate(mode="LDCT", it=0, denoise_result=qry.copy())
+    assert 0 < den.metric_instance["LDCT"]["fsim_iter_0"] <= 1
+
+
+def test_fsim_behaviour():
+    ref, q1 = _pair(256, 7, 0.02)
+    _, q2 = _pair(256, 7, 0.1)
+    assert abs(ev.fsim(ref, ref) - 1.0) < 1e-6
+    f1, f2 = ev.fsim(ref, q1), ev.fsim(ref, q2)
+    assert 0 < f2 < f1 < 1
+    big, bigq = _pair(512, 9, 0.03)                          # 512 -> averaged down by 2 before the analysis
+    assert 0 < ev.fsim(big, bigq) < 1
+    pc = ev._phase_congruency(ref * 255)
+    assert pc.shape == ref.shape and pc.min() >= 0 and pc.max() <= 1 + 1e-6
 
 
 def test_yeo_johnson_round_trip_and_per_slice():
