@@ -19,6 +19,7 @@
 // Textures: point-filtered ones are clamped indexed loads; the linearly filtered area table (.cu:262) is exact float
 // bilinear interpolation (the 8-bit weights of the CUDA texture unit are not modelled).
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include "common.h"
 
@@ -255,6 +256,208 @@ __global__ void __launch_bounds__(TS * TS) art_sweep_kernel(SweepArgs a)
     }
 }
 
+// ---- a whole sweep in ONE launch: the grid stays resident, a pixel's slices and footprint stay in registers
+struct PersistArgs {
+    ArtConst c;
+    const float *lut;
+    const float4 *lines;
+    const ArtView *views;
+    const float *norm;
+    const float *proj;
+    long proj_stride;
+    float *vol;
+    unsigned long long *bins;   // 4 x [B][nr], zero on entry; rotation: scatter v%4, zeroed two views ahead
+    unsigned int *sync;         // SYNC_WORDS words of barrier state (see grid_barrier), zero on entry
+    int na, B;
+    float lamda;
+};
+
+__device__ __forceinline__ unsigned long long coherent_load(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Grid-wide barrier over co-resident workgroups (the launcher checks that the whole grid fits on the chip).
+// Everything the workgroups exchange (the bins) moves through agent-scope atomics and coherent loads, so the barrier
+// needs no cache write-back / invalidate (agent-scope release / acquire fences in every workgroup made the first
+// version take 270 us per view): a wave only has to see its own atomics acknowledged before it arrives.
+// Two levels, because read-modify-writes of ONE address serialise at ~50 ns each (1024 arrivals on one counter: 50 us):
+// groups of 32 workgroups count on their own line, the last of a group counts on the root, the last at the root
+// publishes the generation to every group's flag, and a workgroup polls only its group's flag.
+// Layout of `sync` (uint32, 128-byte lines): [0] abort, [32] root, [64 + 32 g] group g counter, [64 + 32 (64 + g)] flag.
+// The wait is bounded: if it ever expired the abort flag makes every workgroup leave and poison its output.
+constexpr int SYNC_GROUP = 32, SYNC_MAX_GROUPS = 64, SYNC_WORDS = 64 + 32 * 2 * SYNC_MAX_GROUPS;
+
+__device__ __forceinline__ void grid_arrive(unsigned int *sync, unsigned int gen, unsigned int wg, unsigned int nwg)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's atomics / stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const unsigned int g = wg / SYNC_GROUP, ngroups = (nwg + SYNC_GROUP - 1) / SYNC_GROUP;
+        const unsigned int gsize = min((unsigned)SYNC_GROUP, nwg - g * SYNC_GROUP);
+        if (__hip_atomic_fetch_add(sync + 64 + 32 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == gen * gsize) {
+            if (__hip_atomic_fetch_add(sync + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == gen * ngroups) {
+                for (unsigned int i = 0; i < ngroups; ++i)
+                    __hip_atomic_store(sync + 64 + 32 * (SYNC_MAX_GROUPS + i), gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ bool grid_wait(unsigned int *sync, unsigned int gen, unsigned int wg)
+{
+    __shared__ int ok_s;
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const unsigned int *flag = sync + 64 + 32 * (SYNC_MAX_GROUPS + wg / SYNC_GROUP);
+        int ok = 1;
+        long spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1L << 22)) {
+                __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            if ((spins & 1023) == 0 && __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                ok = 0;
+                break;
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+__global__ void __launch_bounds__(256) art_sweep_persistent_kernel(PersistArgs a)
+{
+    __shared__ unsigned long long win[BMAX * WIN];
+    __shared__ float lcorr[BMAX * WIN];
+    __shared__ int wmin_s;
+    const ArtConst &c = a.c;
+    const int tid = threadIdx.y * 16 + threadIdx.x;
+    const int ix = blockIdx.x * 16 + threadIdx.x, iy = blockIdx.y * 16 + threadIdx.y;
+    const bool inside = ix < c.nx && iy < c.ny;
+    const int pix = iy * c.nx + ix;
+    const long np = (long)c.nx * c.ny;
+    const unsigned int nwg = gridDim.x * gridDim.y;
+    const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t bin_n = (size_t)a.B * c.nr;
+    float vol[BMAX];
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) vol[b] = (inside && b < a.B) ? a.vol[b * np + pix] : 0.0f;
+
+    // the footprint of a view depends on nothing the sweep computes: the one of view v+1 is formed while the grid
+    // barrier of view v collects its arrivals
+    float dist = 1.0f, foot[NFOOT] = {0, 0, 0, 0, 0};
+    int sb = 0;
+    if (inside) footprint(c, a.views[0], a.lut, a.lines, ix, iy, dist, sb, foot);
+    for (int v = 0; v < a.na; ++v) {
+        unsigned long long *bins_cur = a.bins + (size_t)(v & 3) * bin_n;
+        unsigned long long *bins_z = a.bins + (size_t)((v + 2) & 3) * bin_n;
+        for (long i = wg * 256 + tid; i < (long)bin_n; i += (long)nwg * 256)
+            __hip_atomic_store(&bins_z[i], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) wmin_s = 0x7fffffff;
+        for (int i = tid; i < BMAX * WIN; i += 256) win[i] = 0ULL;
+        __syncthreads();
+        if (inside) atomicMin(&wmin_s, sb);
+        __syncthreads();
+        const int wmin = wmin_s;
+        if (inside) {
+#pragma unroll
+            for (int b = 0; b < BMAX; ++b) {
+                if (b < a.B && vol[b] != 0.0f) {
+                    const float dv = vol[b] / dist;
+#pragma unroll
+                    for (int k = 0; k < NFOOT; ++k) {
+                        const int is = sb + k;
+                        if (is < 0 || is >= c.nr || foot[k] <= 0.0f || dv == 0.0f) continue;
+                        const unsigned long long q = (unsigned long long)__double2ll_rn((double)(dv * foot[k]) * FIX);
+                        const int j = is - wmin;
+                        if (j < WIN) atomicAdd(&win[b * WIN + j], q);
+                        else atomicAdd(&bins_cur[b * c.nr + is], q);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < a.B * WIN; i += 256) {
+            const unsigned long long q = win[i];
+            const int is = wmin + (i % WIN);
+            if (q != 0ULL && is >= 0 && is < c.nr) atomicAdd(&bins_cur[(i / WIN) * c.nr + is], q);
+        }
+        grid_arrive(a.sync, (unsigned)(v + 1), (unsigned)wg, nwg);
+        float dist_n = 1.0f, foot_n[NFOOT] = {0, 0, 0, 0, 0};
+        int sb_n = 0;
+        if (inside && v + 1 < a.na)
+            footprint(c, a.views[v + 1], a.lut, a.lines + (size_t)(v + 1) * (c.nr + 1), ix, iy, dist_n, sb_n, foot_n);
+        if (!grid_wait(a.sync, (unsigned)(v + 1), (unsigned)wg)) {
+            // cannot happen on a grid the launcher found co-resident; if it does, fail loudly: the volume becomes NaN
+            if (inside)
+                for (int b = 0; b < a.B; ++b) a.vol[b * np + pix] = __builtin_nanf("");
+            return;
+        }
+        // ---- correction of view v for this tile's window, back-projection, update (.cu:385-481)
+        const int w0 = wmin < 0 ? 0 : wmin;
+        for (int i = tid; i < a.B * WIN; i += 256) {
+            const int b = i / WIN, r = w0 + (i % WIN);
+            float cv = 0.0f;
+            if (r < c.nr) {
+                const long long s = (long long)coherent_load(&bins_cur[b * c.nr + r]);
+                const float p = (float)((double)s * UNFIX) * c.geodiv;
+                const float n = a.norm[(size_t)v * c.nr + r];
+                const float m = a.proj[b * a.proj_stride + (long)v * c.nr + r];
+                cv = n > 0.0f ? c.geodiv * ((m - p) / n) : 0.0f;
+            }
+            lcorr[i] = cv;
+        }
+        __syncthreads();
+        if (inside) {
+            const float div = 1.0f / dist;
+            int idx[NFOOT];
+            float nb = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NFOOT; ++k) {
+                idx[k] = clampi(sb + k, 0, c.nr - 1);
+                nb += c.geodiv * div * foot[k];
+            }
+#pragma unroll
+            for (int b = 0; b < BMAX; ++b) {
+                if (b < a.B) {
+                    float bp = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < NFOOT; ++k) {
+                        const int j = idx[k] - w0;
+                        float cv;
+                        if (j >= 0 && j < WIN) {
+                            cv = lcorr[b * WIN + j];
+                        } else {            // a footprint bin outside the tile's window (never in the reference geometry)
+                            const long long s = (long long)coherent_load(&bins_cur[b * c.nr + idx[k]]);
+                            const float p = (float)((double)s * UNFIX) * c.geodiv;
+                            const float n = a.norm[(size_t)v * c.nr + idx[k]];
+                            const float m = a.proj[b * a.proj_stride + (long)v * c.nr + idx[k]];
+                            cv = n > 0.0f ? c.geodiv * ((m - p) / n) : 0.0f;
+                        }
+                        bp += cv * div * foot[k];
+                    }
+                    const float upd = nb > 0.0f ? a.lamda * (bp / nb) : 0.0f;
+                    vol[b] = fmaxf(vol[b] + upd, 0.0f);
+                }
+            }
+        }
+        __syncthreads();        // lcorr / win are rewritten by the next view
+        dist = dist_n;
+        sb = sb_n;
+#pragma unroll
+        for (int k = 0; k < NFOOT; ++k) foot[k] = foot_n[k];
+    }
+    if (inside) {
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b)
+            if (b < a.B) a.vol[b * np + pix] = vol[b];
+    }
+}
+
 struct ProjArgs {
     ArtConst c;
     const float *lut;
@@ -414,6 +617,7 @@ struct ipdm_art_plan {
     float *d_lut = nullptr, *d_norm = nullptr;
     float4 *d_lines = nullptr;
     ArtView *d_views = nullptr;
+    bool persistent_ok = false;     // the 16x16-tile grid of one sweep is co-resident on this device
 };
 
 static int project_bins(ipdm_art_plan *p, const float *d_vol, unsigned long long *bins, int na, int B, hipStream_t st)
@@ -476,6 +680,15 @@ extern "C" int ipdm_art_plan_create(const ipdm_art_geom *g, const float *lut, co
     IPDM_LAUNCH_CHECK();
     IPDM_HIP_CHECK(hipDeviceSynchronize());
     (void)hipFree(bins);
+    {   // can the one-launch sweep hold its whole grid on the chip? (IPDM_ART_PER_VIEW=1 forces one launch per view)
+        int per_cu = 0, dev = 0, cus = 0;
+        IPDM_HIP_CHECK(hipGetDevice(&dev));
+        IPDM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        IPDM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, art_sweep_persistent_kernel, 256, 0));
+        const long tiles = (long)cdiv(g->nx, 16) * cdiv(g->ny, 16);
+        p->persistent_ok = getenv("IPDM_ART_PER_VIEW") == nullptr && tiles <= (long)per_cu * cus &&
+                           tiles <= (long)SYNC_GROUP * SYNC_MAX_GROUPS;
+    }
     *out = p;
     return IPDM_OK;
 }
@@ -496,7 +709,8 @@ constexpr int SQ_BLOCKS = 64;
 struct ArtWs {
     float *x_for, *x_back, *grad;
     float4 *foot;
-    unsigned long long *bins;       // 3 x [nb][nr], rotated by the per-view launches
+    unsigned long long *bins;       // 4 x [nb][nr], rotated by the views
+    unsigned int *sync;             // grid barrier of the one-launch sweep: arrivals, abort flag
     double *partial;
     ArtState *state;
     size_t bytes;
@@ -512,7 +726,8 @@ ArtWs carve(const ipdm_art_plan *p, void *base, int nb)
     w.x_back = (float *)take(nb * np * sizeof(float));
     w.grad = (float *)take(nb * np * sizeof(float));
     w.foot = (float4 *)take(np * 2 * sizeof(float4));
-    w.bins = (unsigned long long *)take((size_t)3 * nb * p->c.nr * sizeof(unsigned long long));
+    w.bins = (unsigned long long *)take((size_t)4 * nb * p->c.nr * sizeof(unsigned long long));
+    w.sync = (unsigned int *)take(SYNC_WORDS * sizeof(unsigned int));
     w.partial = (double *)take((size_t)nb * SQ_BLOCKS * sizeof(double));
     w.state = (ArtState *)take(nb * sizeof(ArtState));
     w.bytes = (size_t)(q - (char *)base);
@@ -558,7 +773,15 @@ extern "C" int ipdm_art_reconstruct(ipdm_art_plan *p, const float *d_proj, float
         float lamda = 0.24f, sigma = 0.8f;           // .cu:727, :839
         for (int it = 0; it < nsart; ++it) {
             IPDM_HIP_CHECK(hipMemcpyAsync(w.x_back, w.x_for, nb * np * sizeof(float), hipMemcpyDeviceToDevice, st));
-            IPDM_HIP_CHECK(hipMemsetAsync(w.bins, 0, 3 * bin_n * sizeof(unsigned long long), st));
+            IPDM_HIP_CHECK(hipMemsetAsync(w.bins, 0, 4 * bin_n * sizeof(unsigned long long), st));
+            if (p->persistent_ok) {
+                // the whole sweep in one launch (grid resident: checked at plan creation)
+                IPDM_HIP_CHECK(hipMemsetAsync(w.sync, 0, SYNC_WORDS * sizeof(unsigned int), st));
+                PersistArgs pa{c, p->d_lut, p->d_lines, p->d_views, p->d_norm, d_proj + b0 * proj_stride, proj_stride,
+                               w.x_for, w.bins, w.sync, na, nb, lamda};
+                hipLaunchKernelGGL(art_sweep_persistent_kernel, tiles, blk, 0, st, pa);
+                IPDM_LAUNCH_CHECK();
+            } else {
             SweepArgs a{c, p->d_lut, p->d_lines, p->d_views, p->d_norm, d_proj + b0 * proj_stride, proj_stride,
                         w.x_for, w.foot, nullptr, nullptr, nullptr, -1, 0, nb, lamda};
             for (int v = 0; v <= na; ++v) {
@@ -568,6 +791,7 @@ extern "C" int ipdm_art_reconstruct(ipdm_art_plan *p, const float *d_proj, float
                 a.bins_cur = w.bins + (size_t)(v % 3) * bin_n;
                 a.bins_next = w.bins + (size_t)((v + 1) % 3) * bin_n;
                 hipLaunchKernelGGL(art_sweep_kernel<TS>, stiles, sblk, 0, st, a);
+            }
             }
             IPDM_LAUNCH_CHECK();
             hipLaunchKernelGGL(art_sq_partial_kernel, dim3(SQ_BLOCKS, nb), dim3(256), 0, st, w.x_for, w.x_back, np, w.partial);
