@@ -59,8 +59,13 @@ def test_project_small_vs_oracle():
     assert np.abs(got - want).max() <= 5e-5 * np.abs(want).max(), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("per_view", [False, True])
 @pytest.mark.parametrize("nsart,ntv", [(1, 0), (3, 0), (3, 2)])
-def test_reconstruct_small_vs_oracle(nsart, ntv):
+def test_reconstruct_small_vs_oracle(nsart, ntv, per_view, monkeypatch):
+    """Both forms of a sweep: the one-launch grid-resident kernel (default when the grid fits the chip) and one launch
+    per view (IPDM_ART_PER_VIEW=1, read at plan creation; also what larger grids fall back to)."""
+    if per_view:
+        monkeypatch.setenv("IPDM_ART_PER_VIEW", "1")
     g, go, lut, betas = _small()
     vol = _phantoms(3, g.nx)
     proj = oa.project(go, lut, betas, vol)
@@ -99,6 +104,13 @@ def test_reconstruct_bit_reproducible_and_per_slice():
     a = plan.reconstruct_device(proj, 2, 1)
     b = plan.reconstruct_device(proj, 2, 1)
     assert torch.equal(a, b)
+    import os
+    os.environ["IPDM_ART_PER_VIEW"] = "1"              # the per-view form computes the same bits
+    try:
+        plan2 = art.ArtPlan(lut, betas, device=DEV, geom=g)
+    finally:
+        del os.environ["IPDM_ART_PER_VIEW"]
+    assert torch.equal(plan2.reconstruct_device(proj, 2, 1), a)
     for i in (0, 7, 9):
         assert torch.equal(plan.reconstruct_device(proj[i:i + 1], 2, 1), a[i:i + 1])
     # the TV-free reconstruction of a projection approaches the volume
