@@ -118,6 +118,28 @@ def test_reconstruct_bit_reproducible_and_per_slice():
     assert np.sqrt(((r - vol) ** 2).mean()) <= 0.05 * vol.max()
 
 
+def test_art_abi_errors_are_status_codes():
+    """Too small a workspace, a shape that does not match the plan, a CPU device: loud, typed failures."""
+    import ctypes as C
+    from ipdm_pytorch_amd import _lib
+    g, go, lut, betas = _small()
+    plan = art.ArtPlan(lut, betas, device=DEV, geom=g)
+    proj = torch.zeros((1, g.na, g.nr), device=DEV)
+    out = torch.zeros((1, g.ny, g.nx), device=DEV)
+    ws = torch.zeros(1024, dtype=torch.uint8, device=DEV)
+    rc = _lib.lib().ipdm_art_reconstruct(plan._plan, _lib.ptr(proj), _lib.ptr(out), 1, 1, 0, 1, _lib.ptr(ws), ws.numel(), None)
+    assert rc < 0 and b"workspace" in _lib.lib().ipdm_last_error()
+    assert _lib.lib().ipdm_art_project(plan._plan, None, _lib.ptr(proj), 1, _lib.ptr(ws), ws.numel(), None) < 0
+    with pytest.raises(ValueError):
+        plan.reconstruct_device(torch.zeros((1, g.na + 1, g.nr)), 1, 0)
+    with pytest.raises(_lib.IpdmError):
+        art.ArtPlan(lut, betas, device="cpu", geom=g)
+    with pytest.raises(_lib.IpdmError):           # geometry rejected by the library
+        bad = art.default_geom(nx=g.nx, nr=g.nr, na=g.na)
+        bad.dr = 0.0
+        art.ArtPlan(lut, betas, device=DEV, geom=bad)
+
+
 def test_recons_torch_call_surface():
     """recons_torch / proj_torch as the reference's pyd exposes them: CPU tensor in -> CPU tensor out, permuted view."""
     g, go, lut, betas = _small()

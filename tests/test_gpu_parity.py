@@ -356,6 +356,11 @@ def test_attention_kernel_split_bf16_x6(B, heads, T, monkeypatch):
     test_attention_kernel(B, heads, T)
 
 
+def test_attention_random_lengths_split_bf16_x6(monkeypatch):
+    monkeypatch.setenv("IPDM_ATTN_SPLIT", "3")
+    test_attention_random_lengths()
+
+
 def test_attention_random_lengths():
     """Seeded random (B, heads, T): every ragged-tail length class of the 64-key tiles and 128/256-query workgroups."""
     from ipdm_pytorch_amd import _lib
@@ -430,6 +435,23 @@ def test_conv_kernel_split_bf16_x6(case, split_bf16):
     """3-piece split-bf16 (6 MFMA terms, f32 accumulate) meets the SAME tolerance as the exact-f32 kernel."""
     split_bf16(3)
     _conv_case(*case, seed=4200 + sum(case[:8]))
+
+
+def test_conv_kernel_random_shapes_split_bf16_x6(split_bf16):
+    """25 seeded random wide 3x3 stride-1 convolutions through the split-bf16 kernel (ragged cin chunks of 16, ragged
+    cout tiles, concat, up-sampling, W % 4 != 0, all prologues) at the exact-f32 kernel's tolerance."""
+    split_bf16(3)
+    rng = np.random.default_rng(771)
+    for i in range(25):
+        cout = int(rng.choice([40, 64, 96, 128, 200, 256]))
+        c1 = int(rng.choice([4, 16, 24, 64, 72, 128, 136, 256]))
+        c2 = int(rng.choice([0, 0, 16, 64])) if c1 % 32 == 0 else 0
+        act = int(rng.choice([0, 1, 2]))
+        B = int(rng.integers(1, 4))
+        Hs, Ws = int(rng.integers(5, 60)), int(rng.integers(5, 80))
+        up = rng.random() < 0.25
+        H, W = (Hs * 2 - int(rng.integers(0, 2)), Ws * 2 - int(rng.integers(0, 2))) if up else (Hs, Ws)
+        _conv_case(B, c1, c2, Hs, Ws, H, W, cout, 3, 1, act, bool(rng.random() < 0.5), seed=3000 + 13 * i)
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
