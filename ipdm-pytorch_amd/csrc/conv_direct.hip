@@ -11,6 +11,10 @@
 //   * weights of the channel chunk sit in LDS as [ch][tap][CO] and are read as broadcast ds_read_b128 (all lanes
 //     the same address); the inner product is v_pk_fma_f32 over cout pairs with the input value broadcast;
 //   * epilogue: + bias (+ residual), 16-byte stores of the 4 pixels per cout.
+// One pass per tile, 3 workgroups per CU.  Two persistent forms were built and measured slower: producer / consumer wave
+// specialisation (25-35 %), and a loop over (tile, chunk) steps that issues the loads of step s+1 before the FMAs of
+// step s (8->8 @2000x912 0.53 vs 0.45 ms, 16->16 @1000x456 0.43 vs 0.30 ms: the 40 prefetched values cost a wave of
+// occupancy per SIMD, and this VALU-bound loop lives on occupancy).
 #include <cstdlib>
 #include "common.h"
 #include "unet_kernels.h"
