@@ -599,6 +599,15 @@ def test_smoke_pipeline_matches_oracle_psnr():
     assert abs(p_hip - p_cpu) <= 1e-4 * abs(p_cpu), (p_hip, p_cpu)
 
 
+def test_pipeline_is_bit_reproducible():
+    """No float atomics anywhere on the path (fixed-order GroupNorm and step statistics, in-order back-projection,
+    counter-based noise): two runs of the reduced end-to-end pipeline give the same bits."""
+    from ipdm_pytorch_amd.denoiser import smoke_pipeline
+    a, _ = smoke_pipeline(DEV)
+    b, _ = smoke_pipeline(DEV)
+    assert np.array_equal(a, b)
+
+
 def test_drop_in_surface():
     """update_opt / reset_opt / result dicts behave as the reference's (Utils/train_test_utils.py:202-211,45-56)."""
     from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
