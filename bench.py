@@ -25,17 +25,41 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA pe
 PEAK_BF16_MFMA_TFLOPS = 2516.8    # same table: the dense bf16 MFMA rate is 16x the f32 one
 
 
+def kernel_source_sha16():
+    """Identity of the build the counters were taken on: sha256 of the dominant kernel's source file."""
+    import hashlib
+    with open(os.path.join(ROOT, "ipdm-pytorch_amd", "csrc", "conv_ws.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def conv_mode():
+    return {"3": "split-bf16-x6", "2": "split-bf16-x3"}.get(os.environ.get("IPDM_CONV_SPLIT", ""), "exact-f32")
+
+
 def measured_traffic():
     """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
-    separate runs over one bench step, tools/profile_round.sh); counters cannot be collected inside a timed run, so the
-    newest committed summary under profiles/ is reported (null when there is none)."""
+    separate runs over one bench step, tools/profile_round.sh + tools/traffic_summary.py); counters cannot be collected
+    inside a timed run, so a committed summary under profiles/ is reported -- but ONLY one that was taken in the mode this
+    process runs in and on this very kernel source (the summary records both); anything else reports null."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    return int(d["traffic_bytes_per_launch"]), os.path.basename(files[-1])
+    sha, mode = kernel_source_sha16(), conv_mode()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        with open(fn) as f:
+            d = json.load(f)
+        if d.get("kernel_source_sha16") == sha and d.get("mode") == mode:
+            return int(d["traffic_bytes_per_launch"]), os.path.basename(fn)
+    return None, None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def dominant_kernel():
@@ -63,19 +87,41 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 leg (N=1 only)")
+    ap.add_argument("--shape", choices=["ref", "alt"], default="ref",
+                    help="ref: the headline (reference geometry 2000x912, full dual-domain sample).  alt: run the TIMED loop on "
+                         "BASELINE config C3's literal shape instead (B x 1152 views x 736 detectors, proj UNet + HIP FBP only) "
+                         "-- for profiling that leg; the default run reports it beside the headline as `alt_shape`")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the B=1 latency and alt-shape legs (N=1 only)")
     return ap.parse_args()
 
 
-def make_inputs(batch, slice_id0, device):
-    """Synthetic 0.25-dose sinograms of ellipse phantoms, keyed by global slice id."""
+def make_inputs(batch, slice_id0, device, geometry=None):
+    """Synthetic 0.25-dose sinograms of ellipse phantoms, keyed by global slice id; `geometry`: FBP
+    geometry keywords (fbp.ALT_GEOMETRY for the 1152 x 736 shape), default = the reference geometry."""
     import numpy as np
     import torch
     from ipdm_pytorch_amd import synth
+    kw = {}
+    if geometry:
+        kw = dict(n_views=geometry["n_views"], n_det=geometry["n_det"], da=geometry["da"], det_offset=geometry["det_offset"],
+                  dtheta_deg=geometry["dtheta_deg"], D=geometry["source_origin"])
     sinos = []
     for b in range(batch):
         sid = slice_id0 + b
-        sinos.append(synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(sid % 16)), seed=sid))
+        sinos.append(synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(sid % 16), **kw), seed=sid))
     return torch.from_numpy(np.stack(sinos))[:, None].to(device)
+
+
+def timed_leg(fn, warmup=1, steps=1):
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
 
 
 def cpu_baseline():
@@ -139,14 +185,18 @@ def main():
     B = args.batch
     n_global = B * world
     lo, hi = idist.shard_range(n_global, rank, world)
+    from ipdm_pytorch_amd.fbp import ALT_GEOMETRY
     den = progressive_domain_denoiser(opt, seed=1234, slice_id0=lo)
-    ldproj = make_inputs(B, lo, device)
+    alt = args.shape == "alt"
+    if alt:
+        den.set_fbp_geometry(**ALT_GEOMETRY)
+    ldproj = make_inputs(B, lo, device, ALT_GEOMETRY if alt else None)
     den.data_sample_load(ldproj=ldproj)
     n_fwd_proj = sum(args.t_start_proj)
-    n_fwd_img = sum(args.t_start_img) + (0 if args.no_ultra else 15)
+    n_fwd_img = 0 if alt else sum(args.t_start_img) + (0 if args.no_ultra else 15)
 
     def step():
-        out = den.progressive_denoiser_device(sharpen_num=70)
+        out = den.proj_denoiser_device()[0] if alt else den.progressive_denoiser_device(sharpen_num=70)
         return idist.all_gather_slices(out, n_global, rank, world)
 
     for _ in range(args.warmup):
@@ -159,7 +209,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        draw0 = den._noise().draw          # first draw index of the last timed step (alt-mode comparison below)
         out = step()
+    draws_per_step = den._noise().draw - draw0
     torch.cuda.synchronize()
     idist.barrier()
     torch.cuda.synchronize()
@@ -192,7 +244,9 @@ def main():
             "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "full dual-domain progressive sample: proj UNet x%d @2000x912 + HIP FBP + img UNet x%d "
+            "config": {"workload": ("BASELINE config C3 shape: proj UNet x%d @1152x736 (views x detectors) + HIP FBP to 512x512, "
+                                    "t_start_proj=%s (NOT the headline)" % (n_fwd_proj, args.t_start_proj)) if alt else
+                                   "full dual-domain progressive sample: proj UNet x%d @2000x912 + HIP FBP + img UNet x%d "
                                    "@512x512, t_start_proj=%s t_start_img=%s ultra=%s" % (
                                        n_fwd_proj, n_fwd_img, args.t_start_proj, args.t_start_img, not args.no_ultra),
                        "slices_per_gpu": B, "global_batch": n_global, "parallelism": "slice-sharded x%d" % world,
@@ -202,21 +256,47 @@ def main():
         line["dtype"] = {"": "f32", "3": "f32 (wide 3x3 convs: 3-piece split-bf16 operands, 6 MFMA terms, f32 accumulate)",
                          "2": "f32 (wide 3x3 convs: 2-piece split-bf16 operands, 3 MFMA terms, f32 accumulate)"}.get(
                              os.environ.get("IPDM_CONV_SPLIT", ""), "f32")
-        if world == 1 and not args.no_alt and not os.environ.get("IPDM_CONV_SPLIT"):
+        if world == 1 and not args.no_extra_legs and not alt and not os.environ.get("IPDM_CONV_SPLIT"):
+            # ---- B = 1 latency (the reference is a one-slice-at-a-time tool): same workload, one slice
+            den.data_sample_load(ldproj=ldproj[:1].contiguous())
+            dt1, _ = timed_leg(lambda: den.progressive_denoiser_device(sharpen_num=70))
+            line["config"]["latency_b1"] = {
+                "s_per_slice": round(dt1, 4), "b8_s_per_slice": round(elapsed / args.steps / B, 4),
+                "ratio_to_b8": round(dt1 / (elapsed / args.steps / B), 3),
+                "note": "one slice alone through the same pipeline (1 warm-up + 1 timed pass)"}
+            # ---- BASELINE config C3 at its literal shape: B x [1152 views x 736 detectors], proj UNet x45 + HIP FBP
+            den.set_fbp_geometry(**ALT_GEOMETRY)
+            den.data_sample_load(ldproj=make_inputs(B, lo, device, ALT_GEOMETRY))
+            dta, oa = timed_leg(lambda: den.proj_denoiser_device()[0])
+            assert tuple(oa.shape) == (B, 1, 512, 512) and bool(torch.isfinite(oa).all())
+            line["alt_shape"] = {
+                "workload": "B=%d sinograms of 1152 views x 736 detectors: proj UNet x%d (t_start_proj=%s, adaptive guidance) + "
+                            "HIP FBP to 512x512 (BASELINE config C3; no reference counterpart: its geometry is fixed at "
+                            "2000x912)" % (B, n_fwd_proj, args.t_start_proj),
+                "value": round(B / dta, 5), "unit": "slices/s", "ms_per_step": round(dta * 1e3, 2), "steps": 1}
+            den.set_fbp_geometry()
+            den.data_sample_load(ldproj=ldproj)
+        if world == 1 and not args.no_alt and not alt and not os.environ.get("IPDM_CONV_SPLIT"):
             # opt-in mode measured beside the headline (never the headline): same workload, same inputs
             del den
             torch.cuda.empty_cache()
             os.environ["IPDM_CONV_SPLIT"] = "3"
             os.environ["IPDM_ATTN_SPLIT"] = "3"
             try:
+                from ipdm_pytorch_amd.diffusion import NoiseSource
                 den2 = progressive_domain_denoiser(opt, seed=1234, slice_id0=lo)
                 den2.data_sample_load(ldproj=ldproj)
                 out2 = den2.progressive_denoiser_device(sharpen_num=70)
+                # the compared pass replays exactly the draws of the headline's last timed step: same seed, same
+                # global slice ids, same draw indices (the counter-based source is a pure function of the three)
+                den2.noise = NoiseSource(1234, lo)
+                den2.noise.draw = draw0
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 out2 = den2.progressive_denoiser_device(sharpen_num=70)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
+                assert den2.noise.draw - draw0 == draws_per_step, "alt mode consumed a different draw range"
                 d = (out2 - out).float()
                 mse = float((d * d).mean())
                 rng = float(out.max() - out.min())
@@ -235,10 +315,11 @@ def main():
             tb, used, cores = cpu_baseline()
             per_slice = n_fwd_proj * tb["proj"] + n_fwd_img * tb["img"] + tb["fbp"]
             line["cpu_baseline"] = {
-                "value": round(1.0 / per_slice, 6), "unit": "slices/s", "cores": used, "host_cores": cores, "kind": "port",
-                "sample": "oracle (torch-CPU fp32 restatement + C FBP) timed on 1 proj-UNet fwd @2000x912 (%.1fs), "
+                "value": round(1.0 / per_slice, 6), "unit": "slices/s", "cores": used, "threads": used, "host_cores": cores,
+                "cpu_model": cpu_model(), "torch": torch.__version__, "kind": "port",
+                "sample": "oracle (torch-CPU fp32 restatement + C FBP, %d torch threads of the host's %d logical cores) timed on 1 proj-UNet fwd @2000x912 (%.1fs), "
                           "1 img-UNet fwd @512x512 (%.1fs, best of 16/32/64 threads), 1 FBP (%.1fs); extrapolated by "
-                          "call counts %d/%d/1 per slice" % (tb["proj"], tb["img"], tb["fbp"], n_fwd_proj, n_fwd_img)}
+                          "call counts %d/%d/1 per slice" % (used, cores, tb["proj"], tb["img"], tb["fbp"], n_fwd_proj, n_fwd_img)}
             line["speedup_vs_cpu_baseline"] = round(value * per_slice, 1)
         print(json.dumps(line))
     if torch.distributed.is_initialized():

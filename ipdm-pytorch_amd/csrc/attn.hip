@@ -355,12 +355,8 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
         // wave-specialised kernel, one 512-thread workgroup per CU.  64 queries per consumer wave (K/V operand reads
         // shared by two query tiles) when the 256-query workgroups come in whole rounds of the CUs, else 32
         constexpr size_t lds = (size_t)2 * (KV * KP + 64 * VP) * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)attention_ws_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)attention_ws_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr = true;
-        }
+        if (int rc = ensure_dynamic_lds((const void *)attention_ws_kernel<64, 1>, lds)) return rc;
+        if (int rc = ensure_dynamic_lds((const void *)attention_ws_kernel<64, 2>, lds)) return rc;
         const long wg2 = (long)cdiv(T, 256) * B * heads, wg1 = (long)cdiv(T, 128) * B * heads;
         const auto eff = [](long wg) { return (double)wg / (double)(((wg + 255) / 256) * 256); };    // round quantisation
         const bool q2 = wg2 >= 256 && eff(wg2) >= eff(wg1) - 0.03;

@@ -292,11 +292,7 @@ int attention_sx_launch(const float *qkv, float *scratch, float *out, int B, int
 {
     IPDM_REQUIRE(scratch, "attention (split-bf16): no scratch for the pre-split K/V pieces");
     constexpr size_t lds = (size_t)2 * STAGE * sizeof(unsigned short);
-    static bool attr = false;
-    if (!attr) {
-        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)attention_sx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
+    if (int rc = ensure_dynamic_lds((const void *)attention_sx_kernel, lds)) return rc;
     unsigned short *pieces = reinterpret_cast<unsigned short *>(scratch);
     hipLaunchKernelGGL(attention_sx_split_kernel, dim3(cdiv(T, KV), B * heads), dim3(256), 0, st, qkv, pieces, heads, T, scale);
     dim3 grid(cdiv(T, 32 * NCONS), B * heads);

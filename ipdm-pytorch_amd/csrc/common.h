@@ -34,6 +34,12 @@ void set_error(const char *fmt, ...);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for kernels that use more than 64 KiB of LDS: set once per
+// (kernel, device), under a lock -- handles may be driven from different threads and devices of one process.
+int ensure_dynamic_lds(const void *kernel, size_t bytes);
+// multiprocessor count of the CURRENT device (cached per device)
+int device_cu_count();
+
 // wave64 reductions (CDNA wavefront = 64 lanes)
 __device__ inline double wave_sum(double v)
 {

@@ -324,12 +324,7 @@ static int launch_conv(const ConvArgs &args, hipStream_t st)
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 31) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 31),
                  "conv2d: per-sample tensor exceeds 32-bit offsets");
     const long nwg = (long)a.tiles_x * a.tiles_y * a.co_tiles * a.B;
-    static bool attr_set = false;
-    if (!attr_set) {
-        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_igemm_kernel<KS, STRIDE, MB, NB, KC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds((const void *)conv_igemm_kernel<KS, STRIDE, MB, NB, KC>, T::LDS_BYTES)) return rc;
     const bool prof = prof_enabled();
     if (prof) prof_before(prof_cls, st);
     hipLaunchKernelGGL((conv_igemm_kernel<KS, STRIDE, MB, NB, KC>), dim3((unsigned)nwg), dim3(256), T::LDS_BYTES, st, a);

@@ -306,15 +306,7 @@ __global__ void __launch_bounds__(256 * CW + 256) conv_sx_kernel(ConvArgs a, int
     }
 }
 
-int sx_num_cus()
-{
-    static int n = 0;
-    if (!n) {
-        int dev = 0, v = 0;
-        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    }
-    return n;
-}
+int sx_num_cus() { return device_cu_count(); }
 
 template <int WM, int NS, int CW>
 int launch_sx(const ConvArgs &args, hipStream_t st)
@@ -335,11 +327,7 @@ int launch_sx(const ConvArgs &args, hipStream_t st)
     const int cus = sx_num_cus();
     int G = (int)(ntiles < cus ? ntiles : cus);
     G = (G + 7) / 8 * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_sx_kernel<WM, NS, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds((const void *)conv_sx_kernel<WM, NS, CW>, lds)) return rc;
     const bool prof = prof_enabled();
     if (prof) prof_before(0, st);
     hipLaunchKernelGGL((conv_sx_kernel<WM, NS, CW>), dim3((unsigned)G), dim3(256 * CW + 256), lds, st, a, (int)ntiles);

@@ -483,19 +483,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     }
 }
 
-int num_cus()
-{
-    static int n = 0;
-    if (!n) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
-    }
-    return n;
-}
+int num_cus() { return device_cu_count(); }
 
 template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4>
 int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
@@ -519,12 +507,7 @@ int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
     const int cus = num_cus();
     int G = (int)(ntiles < cus ? ntiles : cus);
     G = (G + 7) / 8 * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        IPDM_HIP_CHECK(hipFuncSetAttribute((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>, T::LDS_BYTES)) return rc;
     const bool prof = prof_enabled();
     if (prof) prof_before(prof_cls, st);
     hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>), dim3((unsigned)G), dim3(512), T::LDS_BYTES, st, a, (int)ntiles);

@@ -30,6 +30,9 @@ extern "C" int ipdm_fbp_plan_create(const ipdm_fbp_geom *geom, ipdm_fbp_plan **o
     IPDM_REQUIRE(geom && out, "fbp_plan_create: null argument");
     IPDM_REQUIRE(geom->n_views > 1 && geom->n_det > 1 && geom->grid_n > 0 && geom->da > 0,
                  "fbp_plan_create: bad geometry");
+    // the ramp kernel visits only the taps of the parity that is non-zero for an even detector count (h_RL has its
+    // non-zero taps at even indices and at the centre N-1, Recon/FBP_kernel.py:52-56, N = 912 there)
+    IPDM_REQUIRE(geom->n_det % 2 == 0, "fbp_plan_create: n_det %d must be even", geom->n_det);
     ipdm_fbp_plan *p = new ipdm_fbp_plan();
     p->g = *geom;
     const int M = geom->n_views, N = geom->n_det, G = geom->grid_n;

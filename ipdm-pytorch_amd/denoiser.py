@@ -124,7 +124,7 @@ class progressive_domain_denoiser(EvaluationMixin):
         self._fbp = None
         self._art = None
         if convertor == "FBP":
-            self._fbp = FBP(device=self.opt.device)
+            self._fbp = FBP(device=self.opt.device, **(getattr(self, "fbp_geometry", None) or {}))
             self.convertor = self._fbp.convert
         elif convertor == "ART":
             self._art = art._plan_for(*self._art_tables(), torch.device(self.opt.device))
@@ -134,6 +134,13 @@ class progressive_domain_denoiser(EvaluationMixin):
             self.convertor = None
         self.projection = lambda x: art.proj_torch(x, *self._art_tables(), device=self.opt.device)
 
+    def set_fbp_geometry(self, **geometry):
+        """Extension (not in the reference, whose FBP geometry is hard-coded): plan the FBP convertor for another
+        sinogram shape, e.g. fbp.ALT_GEOMETRY (1152 views x 736 detectors); no arguments = the reference geometry."""
+        self.fbp_geometry = dict(geometry) if geometry else None
+        if self.opt.convertor == "FBP":
+            self.init_convertor("FBP")
+
     def _art_tables(self):
         from . import art
         if getattr(self, "_art_tab", None) is None:
@@ -141,16 +148,23 @@ class progressive_domain_denoiser(EvaluationMixin):
         return self._art_tab
 
     def load_model(self):
-        """Utils/train_test_utils.py:247-251 + LoggerX.load_checkpoints (Utils/loggerx.py:71-80): state_dict
-        files save_models/{proj_model,img_model}-{epoch} under the given path."""
+        """Utils/train_test_utils.py:247-251 + LoggerX.load_checkpoints / load_network (Utils/loggerx.py:69-80,131-140):
+        state_dict files `<load path>/{proj_model,img_model}-<epoch>` (what LoggerX.checkpoints writes into its
+        save_models directory), `module.` removed from the keys.  A file that does not exist is skipped as in the
+        reference (osp.exists guard) -- but not silently: the network then keeps its initial weights."""
+        import warnings
         o = self.opt
         for name, model, ep, path in (("img_model", self.img_model, o.resume_epochs_img, o.load_img_model_path),
                                       ("proj_model", self.proj_model, o.resume_epochs_proj, o.load_proj_model_path)):
             if ep > 0 and path is not None and model is not None:
-                f = os.path.join(path, "save_models", "%s-%d" % (name, ep))
-                if not os.path.isfile(f):
-                    f = os.path.join(path, "%s-%d" % (name, ep))
-                model.load_state_dict(torch.load(f, map_location="cpu"))
+                f = os.path.join(path, "%s-%d" % (name, ep))
+                if not os.path.exists(f) and os.path.exists(os.path.join(path, "save_models", "%s-%d" % (name, ep))):
+                    f = os.path.join(path, "save_models", "%s-%d" % (name, ep))      # a run directory was given
+                if not os.path.exists(f):
+                    warnings.warn("checkpoint %s not found: %s keeps its initial weights" % (f, name), UserWarning)
+                    continue
+                sd = torch.load(f, map_location="cpu")
+                model.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
 
     # ------------------------------------------------------------------ temp (:397-419)
     def temp_clear(self):
@@ -297,13 +311,19 @@ class progressive_domain_denoiser(EvaluationMixin):
 
     # ------------------------------------------------------------------ fast path (no host copies)
     @torch.no_grad()
-    def progressive_denoiser_device(self, ldproj=None, sharpen_num=42):
-        """Same arithmetic as progressive_denoiser(save_* = False) with every intermediate kept on the
-        GPU and no result-dict copies: what bench.py times.  Returns the device tensor [B,1,512,512]."""
+    def proj_denoiser_device(self, ldproj=None):
+        """proj_denoiser(convert=True, save_state=False) with nothing copied to the host: the projection-domain loop and
+        the convertor.  Returns (image [B,1,G,G] on the device, noise_strength)."""
         x = self.ldproj if ldproj is None else ldproj
         result, _, n_s = self._proj_dense(x)
         self.noise_strength = n_s
-        img = self._convert_dev(result[-1], 10 if self.opt.clip_proj else 1)
+        return self._convert_dev(result[-1], 10 if self.opt.clip_proj else 1), n_s
+
+    @torch.no_grad()
+    def progressive_denoiser_device(self, ldproj=None, sharpen_num=42):
+        """Same arithmetic as progressive_denoiser(save_* = False) with every intermediate kept on the
+        GPU and no result-dict copies: what bench.py times.  Returns the device tensor [B,1,512,512]."""
+        img, n_s = self.proj_denoiser_device(ldproj)
         if self.opt.convertor == "FBP" and self.opt.fbp_sharpen:
             img = tensor_sharpen(img, sharpen_num)
         if self.opt.normal:

@@ -28,6 +28,13 @@ def _stream():
     return _lib.current_stream()
 
 
+def _dcall(t, name, *args):
+    """Native call on the device (and that device's current stream) of tensor `t`: opt.device='cuda:1' must work
+    without the caller having made it the current device (the reference picks its GPU through opt.device only)."""
+    with torch.cuda.device(t.device):
+        return call(name, *args, _stream())
+
+
 def cosine_lambda(ts, power, i):
     """cosine_beta_schedule(ts, schedule_power=power)[i] (Model/model.py:546,552) as a python float."""
     out = C.c_double()
@@ -48,7 +55,7 @@ class NoiseSource:
     def next_like(self, x):
         out = torch.empty_like(x)
         B = x.shape[0]
-        call("ipdm_randn", ptr(out), B, x.numel() // B, self.seed, self.slice_id0, self.draw, _stream())
+        _dcall(out, "ipdm_randn", ptr(out), B, x.numel() // B, self.seed, self.slice_id0, self.draw)
         self.draw += 1
         return out
 
@@ -107,7 +114,7 @@ class GaussianDiffusion:
     def q_sample(self, x_start, t, noise):
         x = x_start.contiguous()
         out = torch.empty_like(x)
-        call("ipdm_q_sample", self._h, int(t), ptr(x), ptr(noise), ptr(out), x.numel(), _stream())
+        _dcall(x, "ipdm_q_sample", self._h, int(t), ptr(x), ptr(noise), ptr(out), x.numel())
         return out
 
     # ---- Model/model.py:492-515 (per-slice statistics)
@@ -123,11 +130,11 @@ class GaussianDiffusion:
         if isinstance(lambda_, torch.Tensor) and lambda_.dim() > 0:
             lm = lambda_.to(x_t.device, torch.float32).contiguous()
             mh, mw = lm.shape[-2], lm.shape[-1]
-            call("ipdm_ddpm_step", self._h, int(t), ptr(eps_pred), ptr(x_t), ptr(x_0), ptr(noise), ptr(out), B, H, W,
-                 0.0, ptr(lm), mh, mw, 1 if clip_denoised else 0, ptr(ws), ws.numel(), _stream())
+            _dcall(x_t, "ipdm_ddpm_step", self._h, int(t), ptr(eps_pred), ptr(x_t), ptr(x_0), ptr(noise), ptr(out), B, H, W,
+                   0.0, ptr(lm), mh, mw, 1 if clip_denoised else 0, ptr(ws), ws.numel())
         else:
-            call("ipdm_ddpm_step", self._h, int(t), ptr(eps_pred), ptr(x_t), ptr(x_0), ptr(noise), ptr(out), B, H, W,
-                 float(lambda_), None, 0, 0, 1 if clip_denoised else 0, ptr(ws), ws.numel(), _stream())
+            _dcall(x_t, "ipdm_ddpm_step", self._h, int(t), ptr(eps_pred), ptr(x_t), ptr(x_0), ptr(noise), ptr(out), B, H, W,
+                   float(lambda_), None, 0, 0, 1 if clip_denoised else 0, ptr(ws), ws.numel())
         return out
 
     # ---- guidance map after pass 0 (Model/model.py:574-614)
@@ -141,14 +148,14 @@ class GaussianDiffusion:
         p1, p2 = CURVE_COEFFS[mode]
         a1 = (C.c_double * 5)(*p1)
         a2 = (C.c_double * 3)(*p2)
-        call("ipdm_guidance_map", ptr(x.contiguous()), ptr(img.contiguous()), ptr(Lam), ptr(emax), B, H, W, ks,
-             float(amplitude), 0 if mode == "img" else 1, a1, a2, ptr(ws), ws.numel(), _stream())
+        _dcall(x, "ipdm_guidance_map", ptr(x.contiguous()), ptr(img.contiguous()), ptr(Lam), ptr(emax), B, H, W, ks,
+               float(amplitude), 0 if mode == "img" else 1, a1, a2, ptr(ws), ws.numel())
         return Lam, emax
 
     def lambda_ratio(self, Lam, i, ts):
         """condition_lambda_ratio_cuda + clip (Model/model.py:328-351,558) on the small map."""
         out = torch.empty_like(Lam)
-        call("ipdm_lambda_ratio", ptr(Lam), ptr(out), Lam.numel(), int(i), int(ts), _stream())
+        _dcall(Lam, "ipdm_lambda_ratio", ptr(Lam), ptr(out), Lam.numel(), int(i), int(ts))
         return out
 
     # ---- Model/model.py:517-642
@@ -190,7 +197,7 @@ class GaussianDiffusion:
                     reverse_states.append(x.detach().cpu().numpy())
             if clip:
                 y = torch.empty_like(x)
-                call("ipdm_clamp", ptr(x), ptr(y), n, 0 if mode == "img" else 1, _stream())
+                _dcall(x, "ipdm_clamp", ptr(x), ptr(y), n, 0 if mode == "img" else 1)
                 x = y
             if it == 0 and constant_guidance is None:
                 if mode == "img":
@@ -233,7 +240,7 @@ class GaussianDiffusion:
             it += 1
         if len(iters_out) > 1:
             avg = torch.empty_like(iters_out[-1])
-            call("ipdm_axpbypcz", ptr(iters_out[-1]), ptr(iters_out[-2]), None, ptr(avg), n, 0.5, 0.5, 0.0, _stream())
+            _dcall(avg, "ipdm_axpbypcz", ptr(iters_out[-1]), ptr(iters_out[-2]), None, ptr(avg), n, 0.5, 0.5, 0.0)
             iters_out.append(avg)
         if adaptive:
             return iters_out[1:], reverse_states, noise_strength
@@ -263,9 +270,9 @@ class GaussianDiffusion:
             eps_pred = model(x, t)
             z = noise.next_like(x)
             out = torch.empty_like(x)
-            call("ipdm_ddim_step", self._h, t, tp, ptr(eps_pred), ptr(x), ptr(cond), ptr(z) if ddim_eta != 0 else None,
-                 ptr(out), B, x.numel() // B, float(condition_lambda), float(ddim_eta), 1 if clip_denoised else 0,
-                 ptr(ws), ws.numel(), _stream())
+            _dcall(x, "ipdm_ddim_step", self._h, t, tp, ptr(eps_pred), ptr(x), ptr(cond), ptr(z) if ddim_eta != 0 else None,
+                   ptr(out), B, x.numel() // B, float(condition_lambda), float(ddim_eta), 1 if clip_denoised else 0,
+                   ptr(ws), ws.numel())
             x = out
         return x
 
@@ -290,8 +297,8 @@ class GaussianDiffusion:
                                           ddim_discr_method=ddim_discr_method, ddim_eta=ddim_eta, clip_denoised=clip_denoised,
                                           noise=noise)
             nxt = torch.empty_like(sample_img)
-            call("ipdm_axpbypcz", ptr(sample_img), ptr(condition_), None, ptr(nxt), sample_img.numel(), float(eta), float(1 - eta),
-                 0.0, _stream())
+            _dcall(nxt, "ipdm_axpbypcz", ptr(sample_img), ptr(condition_), None, ptr(nxt), sample_img.numel(), float(eta),
+                   float(1 - eta), 0.0)
             condition = nxt
             result.append(sample_img.clone())
         return result
@@ -300,9 +307,8 @@ class GaussianDiffusion:
         """Model/model.py:625-635."""
         out = torch.empty_like(x)
         if mode == "proj":
-            call("ipdm_axpbypcz", ptr(x), ptr(img), None, ptr(out), x.numel(), float(eta), float(1 - eta), 0.0, _stream())
+            _dcall(x, "ipdm_axpbypcz", ptr(x), ptr(img), None, ptr(out), x.numel(), float(eta), float(1 - eta), 0.0)
         else:
             ld = ldct.to(x.device, torch.float32).contiguous()
-            call("ipdm_axpbypcz", ptr(x), ptr(img), ptr(ld), ptr(out), x.numel(), float(eta), float(0.95 - eta), 0.05,
-                 _stream())
+            _dcall(x, "ipdm_axpbypcz", ptr(x), ptr(img), ptr(ld), ptr(out), x.numel(), float(eta), float(0.95 - eta), 0.05)
         return out

@@ -49,8 +49,15 @@ def all_gather_slices(local_out, n_slices, rank, world):
     if x.shape[0] < mx:
         pad = torch.zeros((mx - x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         x = torch.cat([x, pad], 0)
-    out = torch.empty((world * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x)
+    if x.is_cuda and dist.get_backend() == "gloo":
+        # plumbing runs of the N>1 path on a box with fewer GPUs than ranks (IPDM_DIST_BACKEND=gloo): gloo gathers
+        # through host memory; the production backend ("nccl" = RCCL over xGMI) gathers device buffers directly
+        host = torch.empty((world * mx,) + tuple(x.shape[1:]), dtype=x.dtype)
+        dist.all_gather_into_tensor(host, x.cpu())
+        out = host.to(x.device)
+    else:
+        out = torch.empty((world * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x)
     if all(c == mx for c in counts):
         return out
     return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(world)], 0)
@@ -64,6 +71,6 @@ def barrier():
 def max_over_ranks(value, device):
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

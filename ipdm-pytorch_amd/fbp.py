@@ -9,6 +9,14 @@ from . import _lib
 from ._lib import FbpGeom, call, lib, ptr
 
 
+# BASELINE.json's config C3 names 736 x 1152 sinograms: 1152 views of 736 detector channels (the reference's own geometry is
+# fixed at 2000 x 912, Recon/FBP_kernel.py:34-40, so this shape has no reference counterpart -- perf / robustness only).
+# Same source distance, FOV and total fan angle as the reference geometry (912 * 0.0010125 rad spread over 736 channels),
+# 360 degrees in 1152 steps.
+ALT_GEOMETRY = dict(n_views=1152, n_det=736, da=0.0012546, det_offset=3.0, dtheta_deg=0.3125, source_origin=59.5,
+                    fov_half=21.0, grid_n=512)
+
+
 class FBP:
     """FBP(device).convert(pj, flip=True) as in Recon/FBP_kernel.py:27-122.
 

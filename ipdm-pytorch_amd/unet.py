@@ -77,7 +77,7 @@ class UNetModel:
         return collections.OrderedDict((k, v.clone()) for k, v in self._params.items())
 
     def load_state_dict(self, sd, strict=True):
-        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}   # Utils/loggerx.py:131-140
+        sd = {k.replace("module.", ""): v for k, v in sd.items()}   # load_network, Utils/loggerx.py:131-140
         missing = [k for k in self._shapes if k not in sd]
         extra = [k for k in sd if k not in self._shapes]
         if strict and (missing or extra):

@@ -141,7 +141,7 @@ def check_fbp(FB):
 
 def main():
     quick = "--quick" in sys.argv
-    M, FB = ref_shim.load()
+    M, FB = ref_shim.load("numpy")      # full-size maps: the vectorised restatement (make_golden pins it to the py_func)
     U = ref_shim.load_curves()
     check_fbp(FB)
     check_loops(M, U)

@@ -41,10 +41,45 @@ def _lambda_ratio_numpy(I, idx, B, H, W, timesteps, lambda_):
 
 
 class _LambdaKernel:
-    """Stands in for the @cuda.jit object: kernel[grid, block](args...)."""
+    """Stands in for the @cuda.jit object: kernel[grid, block](args...) -> the numpy restatement above (fast; used by
+    oracle/check_vs_reference.py at full size, where a per-pixel python loop takes minutes)."""
 
     def __getitem__(self, cfg):
         return _lambda_ratio_numpy
+
+
+class _PyFuncLaunch:
+    """Runs the BODY of the reference's own numba-CUDA kernel (its `.py_func`, Model/model.py:328-351) as plain
+    python, one simulated thread at a time, with `cuda.grid` / `cuda.gridsize` of the stub module answering for that
+    thread.  The kernel is a grid-stride loop, so only the threads that own at least one element are visited (all the
+    others fall straight through their empty ranges).
+
+    One adjustment, stated: numba types `float64 ** float32` as float64, whereas numpy>=2 *scalars* follow NEP 50 and
+    would compute `python_float ** np.float32` in float32.  The exponent map is therefore handed to the body widened
+    to float64 -- exactly the values numba's promotion produces -- and the result is stored into the caller's float32
+    array as the kernel does."""
+
+    def __init__(self, kernel, cuda_mod):
+        self.body, self.cuda = kernel.py_func, cuda_mod
+
+    def __getitem__(self, cfg):
+        grid, block = cfg
+        total = tuple(int(g) * int(b) for g, b in zip(grid, block))
+
+        def launch(I, idx, B, H, W, timesteps, lambda_):
+            lam64 = np.asarray(lambda_, dtype=np.float64)
+            try:
+                self.cuda.gridsize = lambda n: total
+                for it in range(min(total[2], B)):
+                    for iy in range(min(total[1], H)):
+                        for ix in range(min(total[0], W)):
+                            self.cuda.grid = lambda n, _t=(ix, iy, it): _t
+                            self.body(I, idx, B, H, W, timesteps, lam64)
+            finally:
+                for name in ("grid", "gridsize"):
+                    if hasattr(self.cuda, name):
+                        delattr(self.cuda, name)
+        return launch
 
 
 def install():
@@ -90,16 +125,34 @@ def install():
         sys.path.insert(0, REFERENCE_ROOT)
 
 
-def load():
-    """Returns (Model.model, Recon.FBP_kernel) of the reference, with the numba-CUDA guidance
-    kernel replaced by its numpy restatement so that adaptive guidance runs on CPU."""
+_REF_LAMBDA_KERNEL = None
+
+
+def load(lambda_kernel="py_func"):
+    """Returns (Model.model, Recon.FBP_kernel) of the reference.  The numba-CUDA guidance kernel cannot be launched
+    here; `lambda_kernel` chooses what answers `condition_lambda_ratio_cuda[grid, block](...)`:
+      "py_func" (default, what the golden vectors are generated with): the reference's own kernel body executed per
+                simulated thread (_PyFuncLaunch);
+      "numpy":  the vectorised restatement (_lambda_ratio_numpy), for full-size runs."""
+    global _REF_LAMBDA_KERNEL
     if not reference_available():
         raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
     install()
     import Model.model as M
     import Recon.FBP_kernel as F
-    M.condition_lambda_ratio_cuda = _LambdaKernel()
+    if _REF_LAMBDA_KERNEL is None:
+        _REF_LAMBDA_KERNEL = M.condition_lambda_ratio_cuda          # the stub's _NoCuda wrapper around the real body
+    if lambda_kernel == "py_func":
+        M.condition_lambda_ratio_cuda = _PyFuncLaunch(_REF_LAMBDA_KERNEL, sys.modules["numba.cuda"])
+    else:
+        M.condition_lambda_ratio_cuda = _LambdaKernel()
     return M, F
+
+
+def _absent(what):
+    def raiser(*a, **k):
+        raise RuntimeError("%s is not available in this container" % what)
+    return raiser
 
 
 def load_curves():
@@ -107,7 +160,8 @@ def load_curves():
     needs more stubs (Windows .pyd, skimage, piq, tensorboard)."""
     install()
     for name, attrs in {
-        "Recon.TASART2DNSL0": dict(recons_torch=None, proj_torch=None),
+        "Recon.TASART2DNSL0": dict(recons_torch=_absent("Recon.TASART2DNSL0.recons_torch (Windows .pyd)"),
+                                   proj_torch=_absent("Recon.TASART2DNSL0.proj_torch (Windows .pyd)")),
         "skimage": {},
         "skimage.metrics": dict(structural_similarity=None, peak_signal_noise_ratio=None),
         "piq": dict(vif_p=None, fsim=None),

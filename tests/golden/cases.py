@@ -60,3 +60,38 @@ class noise_feed:
         z = torch.from_numpy(synth.hash_normal(self.shape, self.seed * 1000 + self.count))
         self.count += 1
         return z
+
+
+# End-to-end fixture (tests/golden/pipeline.npz): the reference's own progressive_domain_denoiser driven through
+# proj_denoiser -> FBP convertor -> tensor_sharpen -> img_denoiser (+ultra) (Utils/train_test_utils.py:421-567) at the
+# TRUE geometry (2000x912 -> 512x512) with reduced UNets.  The harness always builds UNetModel with its default 4 heads
+# (Utils/train_test_utils.py:213-245), so the attention levels carry 128 channels (head dim 32).
+PIPE_OPT = dict(
+    mode="test_prog", convertor="FBP", fbp_sharpen=True, ultra_img_denoise=True, normal=False, benchmark_test=False,
+    resume_epochs_proj=0, resume_epochs_img=0,
+    model_channels_proj=32, channel_mult_proj=[0.125, 0.125, 0.125, 0.25, 0.5, 4], attention_resolutions_proj=[16],
+    model_channels_img=32, channel_mult_img=[1, 1, 1, 2, 4], attention_resolutions_img=[8],
+    t_start_proj=[2, 2], t_start_img=[2], sample_method_proj="dense", sample_method_img="dense",
+    constant_guidance_proj=None, constant_guidance_img=0.45, save_it_state_proj=False, save_it_state_img=False)
+PIPE_SEEDS = dict(proj_weights=71, img_weights=72, phantom=1, dose=1, noise=73)
+PIPE_SHARPEN = 70
+
+
+class hashed_noise:
+    """Noise source for the HIP path (next_like) and the oracle (draws(shapes)): draw k = hash_normal(shape of the
+    k-th request, seed*1000+k) -- what make_golden's _NoiseFeed hands the reference in place of torch.randn_like."""
+
+    def __init__(self, seed):
+        self.seed, self.draw = seed, 0
+
+    def next_like(self, x):
+        z = torch.from_numpy(synth.hash_normal(tuple(x.shape), self.seed * 1000 + self.draw)).to(x.device)
+        self.draw += 1
+        return z
+
+
+def pipeline_draw_shapes(opt, proj_shape, img_shape):
+    """Shapes of the randn draws of one progressive_denoiser() call with fixed t_start lists, in call order."""
+    n_proj = sum(t + 1 for t in opt["t_start_proj"])
+    n_img = sum(t + 1 for t in opt["t_start_img"]) + (18 if opt["ultra_img_denoise"] else 0)
+    return [tuple(proj_shape)] * n_proj + [tuple(img_shape)] * n_img

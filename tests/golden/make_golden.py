@@ -316,8 +316,147 @@ def gen_misc():
     mu = torch.from_numpy(synth.hash_uniform((64,), 62) * 1.2 - 0.1)
     from Dataset.npz_data_loader import miu2pixel
     out["miu2pixel"] = miu2pixel(mu.clone()).numpy()
-    # lambda kernel (the numpy restatement in ref_shim of the numba-CUDA body) -- recorded for completeness
+    # condition_lambda_ratio_cuda (Model/model.py:328-351): the reference's OWN kernel body executed per simulated
+    # thread (ref_shim._PyFuncLaunch) at the launch configuration of its call site (:555-557), + the host-side clip
+    lam = (synth.hash_uniform((2, 1, 9, 7), 63) * 3.9 + 0.01).astype(np.float32)      # Lambda(delta) in (0.01, 3.91)
+    out["lambda_in"] = lam
+    for (i, ts) in ((0, 15), (7, 15), (14, 15), (2, 3), (19, 20)):
+        I = np.zeros_like(lam)
+        M.condition_lambda_ratio_cuda[(64, 64, 1), (8, 8, 2)](I, np.array([0, i, i + 1]), 2, 9, 7, ts, lam)
+        out["lambda_raw_i%d_ts%d" % (i, ts)] = I.copy()
+        out["lambda_clip_i%d_ts%d" % (i, ts)] = np.clip(I, 0.05, 0.99)
+        # the vectorised stand-in used for full-size runs must be the same function
+        I2 = np.zeros_like(lam)
+        ref_shim._lambda_ratio_numpy(I2, np.array([0, i, i + 1]), 2, 9, 7, ts, lam)
+        assert np.array_equal(I, I2), "ref_shim numpy restatement != the reference kernel body"
     save("misc", **out)
+
+
+# ------------------------------------------------------------------ 8b. the harness end to end
+def gen_pipeline():
+    """Drives the reference's own progressive_domain_denoiser.progressive_denoiser() (Utils/train_test_utils.py:552-567:
+    proj_denoiser -> convertor (FBP, CPU path) -> tensor_sharpen -> img_denoiser -> ultra) on one synthetic low-dose
+    sinogram at the true geometry with reduced UNets, hashed noise in place of torch.randn_like, and records
+    sub-sampled outputs.  Stubs: dataset/dataloader init (no dataset offline), the pure-python back-projection loop
+    is replaced by its vectorised twin (bit-equal on the pixels gen_fbp() checks)."""
+    import argparse
+    import tempfile
+    from tests.golden.cases import PIPE_OPT, PIPE_SEEDS, PIPE_SHARPEN
+    from Config.default_config import default_cfg, cfg_load
+    import json as _json
+    cwd = os.getcwd()
+    os.chdir(ref_shim.REFERENCE_ROOT)                 # init_convertor reads Recon/Simens_*.txt relative to the cwd
+    orig_randn, orig_fbp_cpu, orig_loader = torch.randn_like, FB.fbp_cpu, U.progressive_domain_denoiser.init_data_loader
+    out = {}
+    try:
+        argv, sys.argv = sys.argv, sys.argv[:1]
+        opt = default_cfg()
+        sys.argv = argv
+        with open(os.path.join(ref_shim.REFERENCE_ROOT, "Config", "Mayo-Config", "test_progressive_option.json")) as f:
+            cfg_load(_json.load(f), opt.__dict__)
+        cfg_load(dict(PIPE_OPT, device="cpu"), opt.__dict__)
+        U.progressive_domain_denoiser.init_data_loader = lambda self: None
+        tmp = tempfile.mkdtemp(prefix="ipdm_golden_")
+        den = U.progressive_domain_denoiser(opt, result_save_path=tmp)
+        for net, seed in ((den.proj_model, PIPE_SEEDS["proj_weights"]), (den.img_model, PIPE_SEEDS["img_weights"])):
+            shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed=seed).items()})
+            net.eval()
+        out["proj_keys"] = np.array(list(den.proj_model.state_dict().keys()))
+        out["img_keys"] = np.array(list(den.img_model.state_dict().keys()))
+        fbp_obj = den.convertor.__self__
+        FB.fbp_cpu = lambda I, BS, pj, phi, r, D, gridN, Mv, N, theta, da, nda: fbp_cpu_vectorised(fbp_obj, pj)
+        sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(PIPE_SEEDS["phantom"])), seed=PIPE_SEEDS["dose"])
+        den.data_sample_load(ldct=None, ldproj=torch.from_numpy(sino)[None, None], fdproj=None, fdct=None)
+        feed = _NoiseFeed(PIPE_SEEDS["noise"])
+        torch.randn_like = feed
+        res = den.progressive_denoiser(sharpen_num=PIPE_SHARPEN)
+        out["a_ndraws"] = np.array(feed.k)
+        out["a_final_sub4"] = res.numpy()[0, 0, ::4, ::4].copy()
+        out["a_final_rows"] = res.numpy()[0, 0, 254:258].copy()
+        out["a_noise_strength"] = np.array(str(den.noise_strength))
+        out["a_conv_keys"] = np.array(sorted(den.proj_denoise_convert2img_result.keys()))
+        out["a_prog_keys"] = np.array(sorted(den.progressive_denoise_result.keys()))
+        out["a_convert_sub8"] = den.proj_denoise_convert2img_result[-1][0, 0, ::8, ::8].copy()
+        out["a_prog_last_sub8"] = den.progressive_denoise_result[-1][0, 0, ::8, ::8].copy()
+        from Dataset.npz_data_loader import miu2pixel
+        ph = miu2pixel(synth.rasterize(synth.ellipse_phantom(PIPE_SEEDS["phantom"])))
+        mse = float(np.mean((miu2pixel(res.numpy()[0, 0]) - ph) ** 2))
+        out["a_psnr_vs_phantom"] = np.array(10 * math.log10(1.0 / mse))
+        print("  pipeline A: draws %d  PSNR vs phantom %.3f dB  noise_strength %s" % (feed.k, out["a_psnr_vs_phantom"], den.noise_strength))
+        # run B: every intermediate kept (save_it_state_* = True, save_proj_state=True): result-dict layout + iterates
+        den.temp_clear()
+        den.update_opt(dict(save_it_state_proj=True, save_it_state_img=True))
+        feed = _NoiseFeed(PIPE_SEEDS["noise"])
+        torch.randn_like = feed
+        res_b = den.progressive_denoiser(save_proj_state=True, sharpen_num=PIPE_SHARPEN)
+        out["b_equals_a"] = np.array(bool(np.array_equal(res_b.numpy(), res.numpy())))
+        for name in ("proj_denoise_result", "proj_denoise_convert2img_result", "progressive_denoise_result",
+                     "img_denoise_result"):
+            d = getattr(den, name)
+            out["b_%s_keys" % name] = np.array(sorted(d.keys()))
+            for k in sorted(d.keys()):
+                a = d[k]
+                out["b_%s_%s" % (name, k)] = a[0, 0, ::32, ::16].copy() if a.shape[-2] > 512 else a[0, 0, ::16, ::16].copy()
+        den.reset_opt()
+    finally:
+        torch.randn_like, FB.fbp_cpu = orig_randn, orig_fbp_cpu
+        U.progressive_domain_denoiser.init_data_loader = orig_loader
+        os.chdir(cwd)
+    save("pipeline", **out)
+
+
+def _ref_denoiser(opt_over):
+    """The reference's progressive_domain_denoiser on CPU with the PIPE_OPT networks (dataset init stubbed)."""
+    import tempfile
+    import json as _json
+    from tests.golden.cases import PIPE_OPT, PIPE_SEEDS
+    from Config.default_config import default_cfg, cfg_load
+    argv, sys.argv = sys.argv, sys.argv[:1]
+    opt = default_cfg()
+    sys.argv = argv
+    with open(os.path.join(ref_shim.REFERENCE_ROOT, "Config", "Mayo-Config", "test_progressive_option.json")) as f:
+        cfg_load(_json.load(f), opt.__dict__)
+    cfg_load(dict(PIPE_OPT, device="cpu", **opt_over), opt.__dict__)
+    U.progressive_domain_denoiser.init_data_loader = lambda self: None
+    den = U.progressive_domain_denoiser(opt, result_save_path=tempfile.mkdtemp(prefix="ipdm_golden_"))
+    for net, seed in ((den.proj_model, PIPE_SEEDS["proj_weights"]), (den.img_model, PIPE_SEEDS["img_weights"])):
+        if net is None:
+            continue
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed=seed).items()})
+        net.eval()
+    return den
+
+
+def gen_pipeline_img():
+    """img_denoiser(mode="img_only") of the reference harness (Utils/train_test_utils.py:482-550: img loop + ultra) on an
+    input that is regenerable from integer hashes (rasterised phantom + hashed noise), so that the oracle and the HIP
+    path start from bit-identical data: pins the image-domain half of the orchestration without the FBP image's
+    summation-order differences in front of 17 network evaluations."""
+    from tests.golden.cases import PIPE_SEEDS
+    cwd = os.getcwd()
+    os.chdir(ref_shim.REFERENCE_ROOT)
+    orig_randn, orig_loader = torch.randn_like, U.progressive_domain_denoiser.init_data_loader
+    out = {}
+    try:
+        den = _ref_denoiser(dict(mode="test_img", save_it_state_img=True))
+        x = synth.rasterize(synth.ellipse_phantom(PIPE_SEEDS["phantom"])) + 0.004 * synth.hash_normal((512, 512), 74)
+        feed = _NoiseFeed(PIPE_SEEDS["noise"] + 2)
+        torch.randn_like = feed
+        res = den.img_denoiser(torch.from_numpy(x.astype(np.float32))[None, None], noise_strength=None, mode="img_only")
+        out["ndraws"] = np.array(feed.k)
+        out["final_sub4"] = res.numpy()[0, 0, ::4, ::4].copy()
+        out["final_rows"] = res.numpy()[0, 0, 254:258].copy()
+        out["keys"] = np.array(sorted(den.img_denoise_result.keys()))
+        for k in sorted(den.img_denoise_result.keys()):
+            out["img_" + k] = den.img_denoise_result[k][0, 0, ::16, ::16].copy()
+        assert len(den.progressive_denoise_result) == 0
+    finally:
+        torch.randn_like = orig_randn
+        U.progressive_domain_denoiser.init_data_loader = orig_loader
+        os.chdir(cwd)
+    save("pipeline_img", **out)
 
 
 # ------------------------------------------------------------------ 9. ART data tables
@@ -352,6 +491,10 @@ def gen_metrics():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:            # python tests/golden/make_golden.py pipeline misc ...
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     gen_schedule()
     gen_groups()
     gen_unet()
@@ -361,6 +504,8 @@ if __name__ == "__main__":
     gen_adaptive()
     gen_sparse()
     gen_misc()
+    gen_pipeline()
+    gen_pipeline_img()
     gen_fbp()
     gen_art_tables()
     gen_metrics()

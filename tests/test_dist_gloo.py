@@ -23,6 +23,64 @@ def _per_slice_work(x, slice_id0):
     return torch.sin(x * (1.0 + ids)) + ids
 
 
+def _oracle_slices(lo, hi):
+    """The per-slice sample itself, restated by the CPU oracle (tiny UNet, proj-domain guided reverse process with
+    adaptive guidance, 2+2 steps): slice s depends on (s, its data, draws keyed by s) only."""
+    import numpy as np
+    from oracle import diffusion as od, unet as ou
+    from ipdm_pytorch_amd import synth
+    from tests.golden.cases import LOOP_CFG
+    cfg = ou.UNetConfig(**LOOP_CFG)
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg), seed=41).items()}
+    sch = od.Schedule(1000, 5)
+    outs = []
+    for sid in range(lo, hi):
+        x = torch.from_numpy(synth.hash_uniform((1, 1, 24, 16), 600 + sid)) * 0.6
+        k = [0]
+
+        def noise_fn():
+            z = torch.from_numpy(synth.hash_normal((1, 1, 24, 16), (700 + sid) * 1000 + k[0]))
+            k[0] += 1
+            return z
+        res, _ = od.guided_reverse_process_slice(sch, lambda xx, t: ou.unet_forward(cfg, sd, xx, t), x, t_start=[2, 2],
+                                                 clip=False, lambda_ratio=1, eta=0.5, mode="proj", constant_guidance=None,
+                                                 noise_fn=noise_fn, kernel_size=4, amplitude=7)
+        outs.append(res[-1])
+    return torch.cat(outs, 0) if outs else torch.empty((0, 1, 24, 16))
+
+
+def _worker_pipeline(rank, world, port, n_slices, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from ipdm_pytorch_amd import dist as idist
+    r, w, _ = idist.init_from_env(backend="gloo")
+    lo, hi = idist.shard_range(n_slices, r, w)
+    out = idist.all_gather_slices(_oracle_slices(lo, hi), n_slices, r, w)
+    idist.barrier()
+    q.put((rank, out))
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_pipeline_output_world2():
+    """The gathered result of two ranks, each running the per-slice sample (the oracle's restatement of it -- no GPU
+    here) on its contiguous shard of 3 slices, equals the one-process result bit for bit: pipeline output through
+    shard_range + the single all-gather, ragged shards (2 + 1)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipeline, args=(r, 2, port, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.set_num_threads(2)
+    want = _oracle_slices(0, 3)
+    assert torch.equal(res[0], want) and torch.equal(res[1], want)
+
+
 def _worker(rank, world, port, n_slices, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))

@@ -393,6 +393,78 @@ def test_attention_softmax_rescale_branch():
     assert (out.cpu()[0, :, 10] - v[0, :, 150].float()).abs().max() < 1e-3
 
 
+def _op_conv(x, w, b, ks, act=0, gamma=None, beta=None, res=None, size=None, x2=None):
+    """One fused convolution through the C ABI (ipdm_op_conv2d): [GN(+SiLU)] -> [nearest upsample] -> conv -> +bias [+res]."""
+    from ipdm_pytorch_amd import _lib
+    B, C1, Hs, Ws = x.shape
+    C2 = 0 if x2 is None else x2.shape[1]
+    H, W = size if size is not None else (Hs, Ws)
+    Cout = w.shape[0]
+    out = torch.empty((B, Cout, H, W), device=DEV)
+    xd, x2d = x.to(DEV).contiguous(), (None if x2 is None else x2.to(DEV).contiguous())
+    rd = None if res is None else res.to(DEV).contiguous()
+    arrs = [None if t is None else np.ascontiguousarray(t.numpy(), dtype=np.float32) for t in (w, b, gamma, beta)]
+    _lib.call("ipdm_op_conv2d", _lib.ptr(xd), C1, _lib.ptr(x2d), C2, B, Hs, Ws, H, W, _lib.ptr(arrs[0]), _lib.ptr(arrs[1]),
+              Cout, ks, 1, act, ou.gn_groups(C1 + C2) if act else 0, _lib.ptr(arrs[2]), _lib.ptr(arrs[3]), _lib.ptr(rd),
+              _lib.ptr(out), _lib.current_stream())
+    return out
+
+
+def test_reference_blocks_golden(golden):
+    """The reference's own ResidualBlock (36 -> 24 channels, GroupNorm groups 36 / 24, 1x1 shortcut), Upsample (nearest to
+    an explicit odd size + conv) and AttentionBlock (T = 35, 117) outputs (ops.npz, generated by importing the
+    reference) against the same blocks composed from the library's fused kernels."""
+    import torch.nn.functional as F
+    from ipdm_pytorch_amd import _lib
+    g = golden("ops")
+    # ---- ResidualBlock (Model/model.py:95-130)
+    keys = [str(k) for k in g["res_keys"]]
+    shapes = dict(zip(keys, [(36,), (36,), (24, 36, 3, 3), (24,), (24, 64), (24,), (24,), (24,), (24, 24, 3, 3), (24,),
+                             (24, 36, 1, 1), (24,)]))
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed=25).items()}
+    x = torch.from_numpy(synth.hash_normal((2, 36, 11, 9), 26))
+    emb = torch.from_numpy(synth.hash_normal((1, 64), 27))
+    bias1 = sd["conv1.2.bias"] + F.linear(F.silu(emb), sd["time_emb.1.weight"], sd["time_emb.1.bias"])[0]
+    h1 = _op_conv(x, sd["conv1.2.weight"], bias1, 3, act=2, gamma=sd["conv1.0.weight"], beta=sd["conv1.0.bias"])
+    sc = _op_conv(x, sd["shortcut.weight"], sd["shortcut.bias"], 1)
+    y = _op_conv(h1.cpu(), sd["conv2.2.weight"], sd["conv2.2.bias"], 3, act=2, gamma=sd["conv2.0.weight"],
+                 beta=sd["conv2.0.bias"], res=sc.cpu())
+    np.testing.assert_allclose(y.cpu().numpy(), g["res_out"], rtol=0, atol=1e-5)
+    # ---- Upsample (Model/model.py:160-171)
+    up = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict({"conv.weight": (8, 8, 3, 3), "conv.bias": (8,)}, seed=23).items()}
+    x = torch.from_numpy(synth.hash_normal((1, 8, 29, 63), 24))
+    y = _op_conv(x, up["conv.weight"], up["conv.bias"], 3, size=(57, 125))
+    np.testing.assert_allclose(y.cpu().numpy(), g["up_out"], rtol=0, atol=1e-5)
+    # ---- AttentionBlock (Model/model.py:135-155)
+    for tag, (C, heads, H, W) in {"attn64": (64, 1, 5, 7), "attn256": (256, 4, 9, 13)}.items():
+        shapes = {"norm.weight": (C,), "norm.bias": (C,), "qkv.weight": (3 * C, C, 1, 1), "proj.weight": (C, C, 1, 1),
+                  "proj.bias": (C,)}
+        sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed=21).items()}
+        x = torch.from_numpy(synth.hash_normal((1, C, H, W), 22))
+        qkv = _op_conv(x, sd["qkv.weight"], None, 1, act=1, gamma=sd["norm.weight"], beta=sd["norm.bias"])
+        a = torch.empty((1, C, H * W), device=DEV)
+        _lib.call("ipdm_op_attention", _lib.ptr(qkv.reshape(1, 3 * C, H * W).contiguous()), _lib.ptr(a), 1, heads,
+                  C // heads, H * W, _lib.current_stream())
+        y = _op_conv(a.reshape(1, C, H, W).cpu(), sd["proj.weight"], sd["proj.bias"], 1, res=x)
+        np.testing.assert_allclose(y.cpu().numpy(), g[tag + "_out"], rtol=0, atol=1e-5)
+
+
+def test_lambda_ratio_kernel_body_golden(gd5, golden):
+    """ipdm_lambda_ratio against the reference's OWN condition_lambda_ratio_cuda body (misc.npz: executed per simulated
+    thread under a stub cuda.grid by tests/golden/make_golden.py) + the host clip [0.05, 0.99] (Model/model.py:558).
+    float64 pow on both sides, float32 store: 1 ulp of float32 at most."""
+    g = golden("misc")
+    lam = torch.from_numpy(g["lambda_in"]).to(DEV)
+    n = 0
+    for key in g.files:
+        if key.startswith("lambda_clip_"):
+            i, ts = int(key.split("_i")[1].split("_")[0]), int(key.split("_ts")[1])
+            got = gd5.lambda_ratio(lam, i, ts).cpu().numpy()
+            assert np.abs(got - g[key]).max() <= 1.2e-7, key
+            n += 1
+    assert n == 5
+
+
 # =========================================================================== UNet
 def _native_unet(kw, seed):
     from ipdm_pytorch_amd.unet import UNetModel
