@@ -169,6 +169,17 @@ int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, int32_t C2,
                    int32_t Ws, int32_t H, int32_t W, const float *w_host, const float *b_host, int32_t Cout,
                    int32_t ksize, int32_t stride, int32_t act, int32_t groups, const float *gamma_host,
                    const float *beta_host, const float *d_res, float *d_out, void *stream);
+/* conv A (+bias, +residual) -> GroupNorm(+SiLU) -> conv B (3x3): the GN -> SiLU -> conv chain of ResidualBlock /
+ * AttentionBlock.norm (Model/model.py:82-130,142-147) with the GroupNorm statistics taken from the per-tile partial
+ * sums conv A's kernel leaves behind (no pass over the activations); *fused_rows receives the number of partial-sum
+ * rows per sample that kernel wrote (0: that kernel family has no fused statistics and the activations were read).
+ *   d_x [B,C,H,W]; wA_host [CA,C,ksA,ksA], wB_host [CB,CA,3,3] HOST, reference layout; d_resA [B,CA,Hm,Wm] or NULL;
+ *   d_mid [B,CA,Hm,Wm] (conv A's output), d_out [B,CB,Hm,Wm]; act: 1 GN, 2 GN+SiLU. */
+int ipdm_op_conv_gn_conv(const float *d_x, int32_t C, int32_t B, int32_t H, int32_t W, const float *wA_host,
+                         const float *bA_host, int32_t CA, int32_t ksA, int32_t strideA, const float *d_resA,
+                         int32_t groups, const float *gamma_host, const float *beta_host, int32_t act,
+                         const float *wB_host, const float *bB_host, int32_t CB, float *d_mid, float *d_out,
+                         int32_t *fused_rows, void *stream);
 /* AttentionBlock core (Model/model.py:148-153): d_qkv [B, heads*3*d, T] (per-head (q,k,v) chunks)
  * -> d_out [B, heads*d, T]. */
 int ipdm_op_attention(const float *d_qkv, float *d_out, int32_t B, int32_t heads, int32_t d, int32_t T,

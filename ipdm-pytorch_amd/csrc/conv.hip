@@ -354,6 +354,16 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
     return IPDM_ERR_UNSUPPORTED;
 }
 
+// mirrors the dispatch of conv2d_launch: rows of fused output statistics of the kernel this convolution runs on
+int conv_stats_rows(const ConvArgs &a)
+{
+    if (conv_sx_pieces(a.w_interleave)) return 0;                       // opt-in split-bf16 kernels: no fused statistics
+    if (a.w_interleave) return conv_ws_stats_rows(a);
+    static const bool no_direct = getenv("IPDM_CONV_NO_DIRECT") != nullptr;
+    if (!no_direct && conv_direct_eligible(a)) return conv_direct_stats_rows(a);
+    return 0;                                                           // legacy 4-wave kernels
+}
+
 int conv_k_chunk() { return 8; }
 int conv_ws_k_chunk(int ks, int interleave) { return conv_sx_pieces(interleave) ? 16 : ((interleave && ks == 1) ? 32 : 8); }
 

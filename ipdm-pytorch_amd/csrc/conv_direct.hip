@@ -29,6 +29,19 @@ namespace {
 constexpr int DT_W = 64, DT_H = 16;
 constexpr int DIN_P = 68;      // LDS row pitch: 16-byte aligned runs of 4 (+ halo)
 
+// 32-lane sums: DPP row rotations inside rows of 16 lanes + ds_swizzle (lane ^ 16); every lane ends with the total
+#define IPDM_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
+__device__ inline float sum_lanes_half(float x)
+{
+    x += IPDM_DPP_F(x, 0x121);                           // row_ror:1
+    x += IPDM_DPP_F(x, 0x122);                           // row_ror:2
+    x += IPDM_DPP_F(x, 0x124);                           // row_ror:4
+    x += IPDM_DPP_F(x, 0x128);                           // row_ror:8
+    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
+    return x;
+}
+#undef IPDM_DPP_F
+
 __device__ inline float silu_d(float v)
 {
     const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * v);
@@ -137,25 +150,54 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(ConvArgs a)
         }
     }
 
-    // ---- epilogue: + bias (+ residual); 4 consecutive pixels per cout
+    // ---- epilogue: + bias (+ residual); 4 consecutive pixels per cout; fused GroupNorm statistics of the output
     const int oy = oy0 + ty, ox = ox0 + tx * 4;
-    if (oy >= a.Ho || ox >= a.Wo) return;
+    const bool in_img = oy < a.Ho && ox < a.Wo;
     const size_t out_plane = (size_t)a.Ho * a.Wo;
     const bool vec = (a.Wo & 3) == 0;                      // ox is a multiple of 4: whole run inside, 16-byte aligned
+    const bool full_tile = oy0 + DT_H <= a.Ho && ox0 + DT_W <= a.Wo;     // uniform: no pixel of the tile needs masking
+    __shared__ float st_lds[4][2][CO][2];                  // [wave][32-lane half][cout][sum, sum of squares]
+    const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
     for (int co = 0; co < CO; ++co) {
         if (co < a.Cout) {
             const float b = a.bias ? a.bias[co] : 0.0f;
             const size_t o = ((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wo + ox;
             f32x4 v = {acc[0][co / 2][co & 1] + b, acc[1][co / 2][co & 1] + b, acc[2][co / 2][co & 1] + b, acc[3][co / 2][co & 1] + b};
-            if (vec) {
-                if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + o);
-                *reinterpret_cast<f32x4 *>(a.out + o) = v;
-            } else {
+            if (in_img) {
+                if (vec) {
+                    if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + o);
+                    *reinterpret_cast<f32x4 *>(a.out + o) = v;
+                } else {
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    if (ox + p < a.Wo) a.out[o + p] = v[p] + (a.res ? a.res[o + p] : 0.0f);
+                    for (int p = 0; p < 4; ++p)
+                        if (ox + p < a.Wo) {
+                            v[p] += a.res ? a.res[o + p] : 0.0f;
+                            a.out[o + p] = v[p];
+                        }
+                }
             }
+            if (a.stats) {
+                if (!full_tile) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) v[p] = (in_img && ox + p < a.Wo) ? v[p] : 0.0f;
+                }
+                float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                float s2 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                s1 = sum_lanes_half(s1);
+                s2 = sum_lanes_half(s2);
+                if ((lane & 31) == 0) { st_lds[wave][lane >> 5][co][0] = s1; st_lds[wave][lane >> 5][co][1] = s2; }
+            }
+        }
+    }
+    if (a.stats) {
+        // one row of partial sums per wave: lane c adds the wave's two half sums (DS operations of a wave execute in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int row = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+        if (lane < 2 * a.Cout) {
+            const int co = lane >> 1, k = lane & 1;
+            a.stats[(((size_t)n * a.stats_rows + row) * a.Cout + co) * 2 + k] = st_lds[wave][0][co][k] + st_lds[wave][1][co][k];
         }
     }
 }
@@ -184,8 +226,12 @@ bool conv_direct_eligible(const ConvArgs &a)
            a.cout_pad >= 16;
 }
 
+int conv_direct_stats_rows(const ConvArgs &a) { return cdiv(a.Wo, DT_W) * cdiv(a.Ho, DT_H) * 4; }
+
 int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
 {
+    IPDM_REQUIRE(!a.stats || a.stats_rows == conv_direct_stats_rows(a), "conv2d: statistics rows %d != %d", a.stats_rows,
+                 conv_direct_stats_rows(a));
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 31) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 31),
                  "conv2d: per-sample tensor exceeds 32-bit offsets");
     if (a.ksize == 1) {     // the 1x1 shortcuts of the narrow levels: pure streaming

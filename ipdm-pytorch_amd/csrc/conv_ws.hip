@@ -112,6 +112,24 @@ __device__ inline f32x2 gn_silu2(f32x2 x, float sc, float sh)
     return z * e;
 }
 
+// ---- cross-lane sums for the fused GroupNorm statistics (epilogue).  DPP row rotations inside rows of 16 lanes, then
+// ds_swizzle (LDS crossbar, no memory) across the two rows of a 32-lane half; every participating lane ends with the total.
+#define IPDM_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
+__device__ inline float sum_lanes_stride4(float x)      // over the 8 lanes {l : l % 4 == lane % 4} of the lane's 32-lane half
+{
+    x += IPDM_DPP_F(x, 0x124);                           // row_ror:4
+    x += IPDM_DPP_F(x, 0x128);                           // row_ror:8
+    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
+    return x;
+}
+__device__ inline float sum_lanes_half(float x)         // over all 32 lanes of the lane's half
+{
+    x += IPDM_DPP_F(x, 0x121);                           // row_ror:1
+    x += IPDM_DPP_F(x, 0x122);                           // row_ror:2
+    return sum_lanes_stride4(x);
+}
+#undef IPDM_DPP_F
+
 template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4>
 __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
 {
@@ -133,7 +151,6 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     const int nchunks = (Ctot + KC - 1) / KC;
     const int S = n_my * nchunks;                  // chunks in this workgroup's stream
     const int plane_bytes = a.Hs * a.Ws * 4;
-
     if (threadIdx.x >= 256) {
         // =========================================================================== PRODUCERS
         // Addressing is VALU-free: buffer loads take a per-thread byte offset that is constant for a tile (input) or
@@ -408,6 +425,26 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                             for (int r = 0; r < 16; ++r) acc[m][q][r] += rv[r];
                         }
                 }
+                if (a.stats) {
+                    // fused GroupNorm statistics of the output, dword-epilogue form: the lane is a pixel, the register a
+                    // cout -> 32-lane sums per register (rare shapes: widths that are not multiples of 4)
+                    float *sb = lds + 2 * T::BUF + swave * 256;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                            for (int q = 0; q < NB; ++q) {
+                                const float v = voffq[q] != OOB ? acc[m][q][r] : 0.0f;
+                                s1 += v;
+                                s2 = fmaf(v, v, s2);
+                            }
+                            s1 = sum_lanes_half(s1);
+                            s2 = sum_lanes_half(s2);
+                            if (l31 == 0) *reinterpret_cast<f32x2 *>(sb + (m * 32 + 8 * (r >> 2) + (r & 3) + 4 * lk) * 2) = f32x2{s1, s2};
+                        }
+                }
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -452,6 +489,14 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 };
 #undef IPDM_XCHG
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                // fused GroupNorm statistics of the output: after the quad transpose a lane holds 4 pixels of ONE cout
+                // (32m + 8g + (l31 & 3) + 4 lk), so the per-cout sums are formed in-lane over the 4 pixels and the NB rows
+                // and only 8 lanes (l31 >> 2) remain to be combined
+                float st1[MB][4], st2[MB][4];
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { st1[m][g] = 0.0f; st2[m][g] = 0.0f; }
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -468,11 +513,46 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                             f32x4 v = block(m, q, g);
                             if (a.res) v += rv[g];
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4[q], so + 8 * g * plane4, 0);
+                            if (a.stats) {
+                                const float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                                const float s2 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                                const bool ok = voff4[q] != OOB;       // the whole run of 4 pixels is inside the image or not
+                                st1[m][g] += ok ? s1 : 0.0f;
+                                st2[m][g] += ok ? s2 : 0.0f;
+                            }
                         }
                     }
+                if (a.stats) {
+                    float *sb = lds + 2 * T::BUF + swave * 256;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float s1 = sum_lanes_stride4(st1[m][g]), s2 = sum_lanes_stride4(st2[m][g]);
+                            if ((l31 >> 2) == 0) *reinterpret_cast<f32x2 *>(sb + (m * 32 + 8 * g + qi + 4 * lk) * 2) = f32x2{s1, s2};
+                        }
+                }
             } else {
                 if (t.co0 + T::BN <= a.Cout) epilogue(std::false_type{});
                 else epilogue(std::true_type{});
+            }
+            if (a.stats) {
+                // the wave's row of partial sums: staged [cout][2] in LDS by the lanes that own a cout, read back as
+                // contiguous runs (DS operations of one wave execute in order) and stored with one instruction
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float *sb = lds + 2 * T::BUF + swave * 256;
+                const int row = ((t.oy0 / T::TH) * a.tiles_x + t.ox0 / T::TW) * 4 + swave;
+                float *dst = a.stats + (((size_t)t.n * a.stats_rows + row) * a.Cout + t.co0) * 2;
+                if (lane * 2 < T::BN) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(sb + lane * 4);       // couts 2 lane, 2 lane + 1
+                    if (VEC4 || t.co0 + T::BN <= a.Cout) *reinterpret_cast<f32x4 *>(dst + lane * 4) = v;
+                    else {
+                        if (t.co0 + 2 * lane < a.Cout) *reinterpret_cast<f32x2 *>(dst + lane * 4) = f32x2{v[0], v[1]};
+                        if (t.co0 + 2 * lane + 1 < a.Cout) *reinterpret_cast<f32x2 *>(dst + lane * 4 + 2) = f32x2{v[2], v[3]};
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_epi += now - t_last; t_last = now; }
@@ -489,7 +569,8 @@ template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4
 int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
 {
     using T = WsTile<KS, STRIDE, MB, NB, KC, IL, PBW>;
-    static_assert(T::LDS_BYTES <= 160 * 1024, "conv_ws: LDS stages exceed 160 KiB");
+    constexpr size_t LDS_TOTAL = T::LDS_BYTES + 4 * 256 * sizeof(float);      // + the statistics rows of the 4 consumer waves
+    static_assert(LDS_TOTAL <= 160 * 1024, "conv_ws: LDS stages exceed 160 KiB");
     ConvArgs a = args;
     // IPDM_CONV_DBG=8: in-kernel s_memtime stamps per phase (tools/bench_conv_dbg.py; needs a.dbg_buf, bench entry only)
     static const int dbg = getenv("IPDM_CONV_DBG") ? atoi(getenv("IPDM_CONV_DBG")) : 0;
@@ -507,10 +588,12 @@ int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
     const int cus = num_cus();
     int G = (int)(ntiles < cus ? ntiles : cus);
     G = (G + 7) / 8 * 8;
-    if (int rc = ensure_dynamic_lds((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>, T::LDS_BYTES)) return rc;
+    IPDM_REQUIRE(!a.stats || a.stats_rows == a.tiles_x * a.tiles_y * 4, "conv2d: statistics rows %d != %d", a.stats_rows,
+                 a.tiles_x * a.tiles_y * 4);
+    if (int rc = ensure_dynamic_lds((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>, LDS_TOTAL)) return rc;
     const bool prof = prof_enabled();
     if (prof) prof_before(prof_cls, st);
-    hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>), dim3((unsigned)G), dim3(512), T::LDS_BYTES, st, a, (int)ntiles);
+    hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>), dim3((unsigned)G), dim3(512), LDS_TOTAL, st, a, (int)ntiles);
     if (prof) prof_after(prof_cls, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
@@ -529,6 +612,19 @@ int launch_ws(const ConvArgs &a, hipStream_t st, int prof_cls)
 }  // namespace
 
 namespace ipdm {
+
+// tile height of the variant conv2d_ws_launch picks (every variant's tile is 32 pixels wide)
+static int ws_tile_rows(const ConvArgs &a)
+{
+    if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 4) {
+        const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128) * a.B;
+        return tiles < 160 ? 4 : 8;
+    }
+    if (a.w_interleave == 2 && a.stride == 1) return 16;      // MB = 2, NB = 4 (3x3 and 1x1)
+    return 8;
+}
+
+int conv_ws_stats_rows(const ConvArgs &a) { return cdiv(a.Ho, ws_tile_rows(a)) * cdiv(a.Wo, 32) * 4; }
 
 // 3x3 stride-1 convolutions with more than 32 output channels (weights packed cout-interleaved, see
 // conv_weight_interleave / conv_pack_weights).

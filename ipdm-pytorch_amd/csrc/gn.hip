@@ -81,9 +81,101 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(GnArgs a)
     }
 }
 
+// Stage A of the fused path: the convolutions that produced the tensor(s) left per-tile partial sums
+// [B][rows][C][2] (float32); block (s, n) folds its share of the rows of both sources into float64 per-group partials in
+// the layout gn_finalize_kernel reads.  A thread always owns the same channel (row-major [row][channel] blocks of
+// 256 / Cp rows), so every sum is formed in a fixed order: results are bit-reproducible.
+__global__ void __launch_bounds__(256) gn_tile_reduce_kernel(GnTileArgs a, int split)
+{
+    const int s = blockIdx.x, n = blockIdx.y;
+    const int Ctot = a.src[0].C + (a.nsrc > 1 ? a.src[1].C : 0);
+    const int cpg = Ctot / a.groups;
+    __shared__ double lsum[256], lsq[256];
+    __shared__ double gsum[512], gsq[512];          // per group (groups <= 512: gn_tiles_launch checks)
+    for (int g = threadIdx.x; g < a.groups; g += 256) { gsum[g] = 0.0; gsq[g] = 0.0; }
+    int cbase = 0;
+    for (int k = 0; k < a.nsrc; ++k) {
+        const GnTileSrc src = a.src[k];
+        const int per = (src.rows + split - 1) / split;
+        const int r0 = s * per, r1 = min(src.rows, r0 + per);
+        for (int c0 = 0; c0 < src.C; c0 += 256) {               // channel chunks of <= 256
+            const int cw = min(256, src.C - c0);
+            int cp = 1;
+            while (cp < cw) cp <<= 1;                             // channels of the chunk, rounded up to a power of two
+            const int rpi = 256 / cp;                             // rows per iteration
+            const int c = threadIdx.x % cp, ro = threadIdx.x / cp;
+            double sum = 0.0, sq = 0.0;
+            if (c < cw) {
+                const float2 *p = reinterpret_cast<const float2 *>(src.stats) + ((size_t)n * src.rows) * src.C + c0 + c;
+                int r = r0 + ro;
+                for (; r + 3 * rpi < r1; r += 4 * rpi) {          // four independent loads in flight
+                    const float2 v0 = p[(size_t)r * src.C], v1 = p[(size_t)(r + rpi) * src.C],
+                                 v2 = p[(size_t)(r + 2 * rpi) * src.C], v3 = p[(size_t)(r + 3 * rpi) * src.C];
+                    sum += (double)v0.x + (double)v1.x + (double)v2.x + (double)v3.x;
+                    sq += (double)v0.y + (double)v1.y + (double)v2.y + (double)v3.y;
+                }
+                for (; r < r1; r += rpi) {
+                    const float2 v = p[(size_t)r * src.C];
+                    sum += (double)v.x;
+                    sq += (double)v.y;
+                }
+            }
+            __syncthreads();                                      // previous chunk's lsum consumed
+            lsum[threadIdx.x] = sum;
+            lsq[threadIdx.x] = sq;
+            __syncthreads();
+            // channel totals of the chunk -> their groups, in a fixed order: thread c folds its channel's row offsets
+            if (threadIdx.x < cw) {
+                double cs = 0.0, cq = 0.0;
+                for (int j = 0; j < rpi; ++j) { cs += lsum[j * cp + threadIdx.x]; cq += lsq[j * cp + threadIdx.x]; }
+                lsum[threadIdx.x] = cs;                           // (own slot j = 0 only: no other thread reads it before the barrier)
+                lsq[threadIdx.x] = cq;
+            }
+            __syncthreads();
+            // one thread per group touched by this chunk adds the chunk's channels of its group, ascending
+            const int g_lo = (cbase + c0) / cpg, g_hi = (cbase + c0 + cw - 1) / cpg;
+            for (int g = g_lo + threadIdx.x; g <= g_hi; g += 256) {
+                const int ca = max(g * cpg, cbase + c0) - (cbase + c0), cb = min((g + 1) * cpg, cbase + c0 + cw) - (cbase + c0);
+                double cs = gsum[g], cq = gsq[g];
+                for (int cc = ca; cc < cb; ++cc) { cs += lsum[cc]; cq += lsq[cc]; }
+                gsum[g] = cs;
+                gsq[g] = cq;
+            }
+        }
+        cbase += src.C;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < a.groups; g += 256) {
+        double *p = a.partials + (((size_t)n * a.groups + g) * GN_SPLIT + s) * 2;
+        p[0] = gsum[g];
+        p[1] = gsq[g];
+    }
+}
+
 }  // namespace
 
 namespace ipdm {
+
+int gn_tiles_launch(const GnTileArgs &a, hipStream_t st)
+{
+    IPDM_REQUIRE(a.nsrc >= 1 && a.nsrc <= 2 && a.src[0].stats && (a.nsrc == 1 || a.src[1].stats) && a.gamma && a.beta &&
+                     a.partials && a.scale && a.shift, "gn_tiles: null argument");
+    const int Ctot = a.src[0].C + (a.nsrc > 1 ? a.src[1].C : 0);
+    IPDM_REQUIRE(a.groups > 0 && a.groups <= 512 && Ctot % a.groups == 0, "gn_tiles: %d channels not divisible by %d groups",
+                 Ctot, a.groups);
+    int rows = a.src[0].rows;
+    if (a.nsrc > 1 && a.src[1].rows > rows) rows = a.src[1].rows;
+    int split = (rows + 63) / 64;                 // >= 64 rows per block
+    split = split < 1 ? 1 : (split > GN_SPLIT ? GN_SPLIT : split);
+    hipLaunchKernelGGL(gn_tile_reduce_kernel, dim3(split, a.B), dim3(256), 0, st, a, split);
+    GnArgs f;
+    f.x1 = f.x2 = nullptr;
+    f.C1 = Ctot; f.C2 = 0; f.B = a.B; f.HW = a.HW; f.groups = a.groups; f.gamma = a.gamma; f.beta = a.beta; f.eps = a.eps;
+    f.partials = a.partials; f.scale = a.scale; f.shift = a.shift; f.split = split;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(64), 0, st, f);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
 
 size_t gn_partials_bytes(int B, int groups) { return (size_t)B * groups * GN_SPLIT * 2 * sizeof(double); }
 

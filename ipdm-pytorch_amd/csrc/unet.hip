@@ -331,7 +331,11 @@ struct Arena {
     }
 };
 
-struct Tensor { size_t off = (size_t)-1; size_t bytes = 0; int C = 0, H = 0, W = 0; int refs = 0; bool external = false; const float *ext = nullptr; };
+// st[]: where the per-tile partial sums of this tensor's channels live (written by the convolution that produced it,
+// ConvArgs::stats); a materialised channel concat refers to the rows of its two sources (nst = 2).  nst = 0: none.
+struct StatRef { size_t off = 0; int rows = 0, C = 0; };
+struct Tensor { size_t off = (size_t)-1; size_t bytes = 0; int C = 0, H = 0, W = 0; int refs = 0; bool external = false; const float *ext = nullptr;
+                size_t st_off = (size_t)-1, st_bytes = 0; StatRef st[2]; int nst = 0; };
 
 }  // namespace
 
@@ -348,6 +352,7 @@ struct ipdm_unet {
     float *temb_W = nullptr, *temb_b = nullptr, *conv1_b = nullptr;   // concatenated over all ResidualBlocks
     int temb_rows = 0;
     int max_gn_groups = 32, max_ch = 0;
+    bool no_fused_stats = false;                // IPDM_GN_UNFUSED=1: GroupNorm statistics by a pass over the activations (gn_partial)
 
     // forward state
     Arena arena;
@@ -538,6 +543,7 @@ struct Fwd {
     {
         if (--t->refs == 0) {
             if (!t->external) net->arena.release(t->off, t->bytes);
+            if (t->st_off != (size_t)-1) net->arena.release(t->st_off, t->st_bytes);
             for (size_t i = 0; i < net->live.size(); ++i)
                 if (net->live[i] == t) { net->live.erase(net->live.begin() + i); break; }
             delete t;
@@ -547,6 +553,24 @@ struct Fwd {
     void gn(const Tensor *x1, const Tensor *x2, const NormP &np)
     {
         if (rc || net->dry) return;
+        // statistics from the per-tile partial sums the producing convolutions left behind, when every source has them
+        StatRef refs[2];
+        int nref = 0;
+        bool have = !net->no_fused_stats;
+        for (const Tensor *t : {x1, x2}) {
+            if (!t) continue;
+            if (t->nst == 0 || nref + t->nst > 2) { have = false; break; }
+            for (int k = 0; k < t->nst; ++k) refs[nref++] = t->st[k];
+        }
+        if (have) {
+            GnTileArgs g;
+            g.nsrc = nref;
+            for (int k = 0; k < nref; ++k) { g.src[k].stats = (const float *)(net->ws + refs[k].off); g.src[k].rows = refs[k].rows; g.src[k].C = refs[k].C; }
+            g.B = net->B; g.HW = (long)x1->H * x1->W; g.groups = np.groups; g.gamma = np.g; g.beta = np.b; g.eps = 1e-5f;
+            g.partials = net->gn_part; g.scale = net->gn_scale; g.shift = net->gn_shift;
+            rc = gn_tiles_launch(g, net->st);
+            return;
+        }
         GnArgs a;
         a.x1 = ptr(x1); a.x2 = x2 ? ptr(x2) : nullptr;
         a.C1 = x1->C; a.C2 = x2 ? x2->C : 0; a.B = net->B;
@@ -557,16 +581,31 @@ struct Fwd {
     }
 
     // conv over (x1 [,x2]) optionally nearest-upsampled to (H,W); returns a new tensor
+    // want_stats: the output feeds a GroupNorm -> the kernel also leaves per-tile partial sums of it (when it can)
     Tensor *conv(const Tensor *x1, const Tensor *x2, const ConvP &cp, int stride, int act, const float *bias,
-                 const Tensor *res, int H, int W, float *ext_out = nullptr)
+                 const Tensor *res, int H, int W, float *ext_out = nullptr, bool want_stats = false)
     {
         const int pad = cp.ks / 2;
         const int Ho = (H + 2 * pad - cp.ks) / stride + 1, Wo = (W + 2 * pad - cp.ks) / stride + 1;
         Tensor *o;
         if (ext_out) { o = new Tensor(); o->C = cp.cout; o->H = Ho; o->W = Wo; o->external = true; o->ext = ext_out; o->refs = 1; net->live.push_back(o); }
         else o = make(cp.cout, Ho, Wo);
-        if (rc || net->dry) return o;
         ConvArgs a;
+        // (shape fields first: the statistics geometry depends on the kernel the dispatcher picks, in dry runs too)
+        a.C1 = x1->C; a.C2 = x2 ? x2->C : 0; a.B = net->B; a.Cout = cp.cout; a.ksize = cp.ks; a.stride = stride; a.Ho = Ho; a.Wo = Wo;
+        a.w_interleave = cp.interleave; a.cout_pad = cp.cout_pad;
+        if (want_stats && !ext_out && !net->no_fused_stats) {
+            const int rows = conv_stats_rows(a);
+            if (rows > 0) {
+                o->st_bytes = (size_t)net->B * rows * cp.cout * 2 * sizeof(float);
+                o->st_off = net->arena.alloc(o->st_bytes);
+                if (o->st_off == (size_t)-1) { set_error("unet_forward: workspace exhausted"); rc = IPDM_ERR_WORKSPACE; o->st_off = 0; }
+                o->nst = 1;
+                o->st[0].off = o->st_off; o->st[0].rows = rows; o->st[0].C = cp.cout;
+            }
+        }
+        if (rc || net->dry) return o;
+        if (o->nst) { a.stats = (float *)(net->ws + o->st_off); a.stats_rows = o->st[0].rows; }
         a.x1 = ptr(x1); a.x2 = x2 ? ptr(x2) : nullptr;
         a.C1 = x1->C; a.C2 = x2 ? x2->C : 0; a.B = net->B;
         a.Hs = x1->H; a.Ws = x1->W; a.H = H; a.W = W;
@@ -587,7 +626,7 @@ struct Fwd {
         const ResP &rp = net->res[l.prefix];
         const int H = x1->H, W = x1->W;
         gn(x1, x2, rp.n1);
-        Tensor *h1 = conv(x1, x2, rp.c1, 1, 2, net->bias_eff + rp.bias_off, nullptr, H, W);
+        Tensor *h1 = conv(x1, x2, rp.c1, 1, 2, net->bias_eff + rp.bias_off, nullptr, H, W, nullptr, true);
         Tensor *sc = nullptr;
         const Tensor *resid;
         if (rp.has_sc) { sc = conv(x1, x2, rp.sc, 1, 0, rp.sc.b, nullptr, H, W); resid = sc; }
@@ -601,7 +640,7 @@ struct Fwd {
             resid = sc;
         } else resid = x1;
         gn(h1, nullptr, rp.n2);
-        Tensor *o = conv(h1, nullptr, rp.c2, 1, 2, rp.c2.b, resid, H, W);
+        Tensor *o = conv(h1, nullptr, rp.c2, 1, 2, rp.c2.b, resid, H, W, nullptr, true);
         release(h1);
         if (sc) release(sc);
         return o;
@@ -623,7 +662,7 @@ struct Fwd {
         if (!rc && !net->dry) rc = attention_launch(ptr(qkv), wptr(a), net->B, heads, hd, H * W, net->st, scr ? wptr(scr) : nullptr);
         if (scr) release(scr);
         release(qkv);
-        Tensor *o = conv(a, nullptr, ap.proj, 1, 0, ap.proj.b, x, H, W);
+        Tensor *o = conv(a, nullptr, ap.proj, 1, 0, ap.proj.b, x, H, W, nullptr, true);
         release(a);
         return o;
     }
@@ -650,6 +689,7 @@ struct Fwd {
                 int g = cdiv(total, 1024); if (g > 4096) g = 4096;
                 hipLaunchKernelGGL(concat_kernel, dim3(g), dim3(256), 0, net->st, ptr(x1), ptr(x2), wptr(cat), x1->C, x2->C, (long)x1->H * x1->W, total);
             }
+            if (x1->nst == 1 && x2->nst == 1) { cat->nst = 2; cat->st[0] = x1->st[0]; cat->st[1] = x2->st[0]; }   // rows stay owned by x1 / x2
             x1 = cat;
             x2 = nullptr;
         }
@@ -659,9 +699,9 @@ struct Fwd {
             const Tensor *in2 = h ? nullptr : x2;
             Tensor *o = nullptr;
             switch (l.kind) {
-                case L_CONV: { const ConvP &cp = net->convs[l.prefix]; o = conv(in1, in2, cp, 1, 0, cp.b, nullptr, in1->H, in1->W); break; }
-                case L_DOWN: { const ConvP &cp = net->convs[l.prefix]; o = conv(in1, in2, cp, 2, 0, cp.b, nullptr, in1->H, in1->W); break; }
-                case L_UP: { const ConvP &cp = net->convs[l.prefix]; o = conv(in1, in2, cp, 1, 0, cp.b, nullptr, size_h, size_w); break; }
+                case L_CONV: { const ConvP &cp = net->convs[l.prefix]; o = conv(in1, in2, cp, 1, 0, cp.b, nullptr, in1->H, in1->W, nullptr, true); break; }
+                case L_DOWN: { const ConvP &cp = net->convs[l.prefix]; o = conv(in1, in2, cp, 2, 0, cp.b, nullptr, in1->H, in1->W, nullptr, true); break; }
+                case L_UP: { const ConvP &cp = net->convs[l.prefix]; o = conv(in1, in2, cp, 1, 0, cp.b, nullptr, size_h, size_w, nullptr, true); break; }
                 case L_RES: o = res_block(in1, in2, l); break;
                 case L_ATTN: o = attn_block(in1, l); break;
             }
@@ -687,6 +727,7 @@ int run_forward(ipdm_unet *net, const float *d_x, int t, float *d_eps, int B, in
                 hipStream_t st, bool dry, size_t *need)
 {
     net->B = B; net->st = st; net->dry = dry; net->ws = (char *)d_ws;
+    net->no_fused_stats = getenv("IPDM_GN_UNFUSED") != nullptr;
     const size_t fixed = fixed_ws_bytes(net, B);
     if (!dry && ws_bytes < fixed) { set_error("unet_forward: workspace too small"); return IPDM_ERR_WORKSPACE; }
     // fixed region
@@ -816,6 +857,80 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
     IPDM_HIP_CHECK(hipStreamSynchronize(st));
     (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_g); (void)hipFree(d_be); (void)hipFree(d_sc); (void)hipFree(d_sh);
     (void)hipFree(d_part);
+    return rc;
+}
+
+// x -> convA (+bias, +residual) -> GroupNorm(+SiLU) from convA's FUSED per-tile statistics -> convB 3x3: the
+// statistics hand-over between a producing convolution and the GroupNorm that follows it, as the executor wires it.
+extern "C" int ipdm_op_conv_gn_conv(const float *d_x, int32_t C, int32_t B, int32_t H, int32_t W, const float *wA_host,
+                                    const float *bA_host, int32_t CA, int32_t ksA, int32_t strideA, const float *d_resA,
+                                    int32_t groups, const float *gamma_host, const float *beta_host, int32_t act,
+                                    const float *wB_host, const float *bB_host, int32_t CB, float *d_mid, float *d_out,
+                                    int32_t *fused_rows, void *stream)
+{
+    IPDM_REQUIRE(d_x && wA_host && wB_host && gamma_host && beta_host && d_mid && d_out && groups > 0, "op_conv_gn_conv: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int padA = ksA / 2;
+    const int Hm = (H + 2 * padA - ksA) / strideA + 1, Wm = (W + 2 * padA - ksA) / strideA + 1;
+    std::vector<float> pA, pB;
+    int cinp, coutpA, coutpB;
+    const int ilA = conv_weight_interleave(CA, ksA, strideA), ilB = conv_weight_interleave(CB, 3, 1);
+    conv_pack_weights(wA_host, CA, C, ksA, ilA, pA, cinp, coutpA);
+    conv_pack_weights(wB_host, CB, CA, 3, ilB, pB, cinp, coutpB);
+    std::vector<void *> tofree;
+    auto dev = [&](const void *h, size_t bytes, void **out) -> int {
+        void *d = nullptr;
+        IPDM_HIP_CHECK(hipMalloc(&d, bytes ? bytes : 4));
+        if (h) IPDM_HIP_CHECK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+        tofree.push_back(d);
+        *out = d;
+        return IPDM_OK;
+    };
+    float *d_wA, *d_wB, *d_bA = nullptr, *d_bB = nullptr, *d_g, *d_be, *d_sc, *d_sh, *d_stats = nullptr;
+    double *d_part;
+    int rc = dev(pA.data(), pA.size() * 4, (void **)&d_wA);
+    if (!rc) rc = dev(pB.data(), pB.size() * 4, (void **)&d_wB);
+    if (!rc && bA_host) rc = dev(bA_host, CA * 4, (void **)&d_bA);
+    if (!rc && bB_host) rc = dev(bB_host, CB * 4, (void **)&d_bB);
+    if (!rc) rc = dev(gamma_host, CA * 4, (void **)&d_g);
+    if (!rc) rc = dev(beta_host, CA * 4, (void **)&d_be);
+    if (!rc) rc = dev(nullptr, (size_t)B * CA * 4, (void **)&d_sc);
+    if (!rc) rc = dev(nullptr, (size_t)B * CA * 4, (void **)&d_sh);
+    if (!rc) rc = dev(nullptr, gn_partials_bytes(B, groups), (void **)&d_part);
+    ConvArgs a;
+    a.x1 = d_x; a.x2 = nullptr; a.C1 = C; a.C2 = 0; a.B = B; a.Hs = H; a.Ws = W; a.H = H; a.W = W; a.upsample = 0;
+    a.scale_y = a.scale_x = 1.f; a.w = d_wA; a.cout_pad = coutpA; a.w_interleave = ilA; a.bias = d_bA; a.Cout = CA; a.ksize = ksA;
+    a.stride = strideA; a.Ho = Hm; a.Wo = Wm; a.act = 0; a.gn_scale = a.gn_shift = nullptr; a.res = d_resA; a.out = d_mid;
+    a.tiles_x = a.tiles_y = a.co_tiles = 0;
+    const int rows = conv_stats_rows(a);
+    if (fused_rows) *fused_rows = rows;
+    if (!rc && rows > 0) {
+        rc = dev(nullptr, (size_t)B * rows * CA * 2 * 4, (void **)&d_stats);
+        if (!rc) IPDM_HIP_CHECK(hipMemsetAsync(d_stats, 0xff, (size_t)B * rows * CA * 2 * 4, st));     // NaN: unwritten rows show
+        a.stats = d_stats; a.stats_rows = rows;
+    }
+    if (!rc) rc = conv2d_launch(a, st);
+    if (!rc && rows > 0) {
+        GnTileArgs g;
+        g.nsrc = 1; g.src[0].stats = d_stats; g.src[0].rows = rows; g.src[0].C = CA; g.B = B; g.HW = (long)Hm * Wm; g.groups = groups;
+        g.gamma = d_g; g.beta = d_be; g.eps = 1e-5f; g.partials = d_part; g.scale = d_sc; g.shift = d_sh;
+        rc = gn_tiles_launch(g, st);
+    } else if (!rc) {
+        GnArgs g;
+        g.x1 = d_mid; g.x2 = nullptr; g.C1 = CA; g.C2 = 0; g.B = B; g.HW = (long)Hm * Wm; g.groups = groups; g.gamma = d_g; g.beta = d_be;
+        g.eps = 1e-5f; g.partials = d_part; g.scale = d_sc; g.shift = d_sh;
+        rc = gn_stats_launch(g, st);
+    }
+    if (!rc) {
+        ConvArgs b;
+        b.x1 = d_mid; b.x2 = nullptr; b.C1 = CA; b.C2 = 0; b.B = B; b.Hs = Hm; b.Ws = Wm; b.H = Hm; b.W = Wm; b.upsample = 0;
+        b.scale_y = b.scale_x = 1.f; b.w = d_wB; b.cout_pad = coutpB; b.w_interleave = ilB; b.bias = d_bB; b.Cout = CB; b.ksize = 3;
+        b.stride = 1; b.Ho = Hm; b.Wo = Wm; b.act = act; b.gn_scale = d_sc; b.gn_shift = d_sh; b.res = nullptr; b.out = d_out;
+        b.tiles_x = b.tiles_y = b.co_tiles = 0;
+        rc = conv2d_launch(b, st);
+    }
+    (void)hipStreamSynchronize(st);
+    for (void *d : tofree) (void)hipFree(d);
     return rc;
 }
 

@@ -23,6 +23,12 @@ struct ConvArgs {
     const float *res;            // [B,Cout,Ho,Wo] or null
     float *out;
     int tiles_x, tiles_y, co_tiles;     // filled by the launcher
+    // Fused GroupNorm statistics of the OUTPUT (for the GroupNorm that follows this convolution): when non-null, every
+    // (tile, consumer wave) / workgroup writes one row of per-channel partial sums {sum, sum of squares} of the final
+    // output values it produced: stats[((n * stats_rows + row) * Cout + c) * 2 + {0,1}] (float32 partials over <= a few
+    // hundred pixels; combined in float64 by gn_tiles_launch).  stats_rows = conv_stats_rows(args).
+    float *stats = nullptr;
+    int stats_rows = 0;
     int dbg = 0;                        // IPDM_CONV_DBG bit mask (kernel experiments only; 0 on the product path)
     unsigned long long *dbg_buf = nullptr;   // dbg & 8: per-workgroup cycle stamps [grid][4]
 };
@@ -62,6 +68,24 @@ struct GnArgs {
     int split = 0;               // workgroups per (sample, group), chosen by the launcher (<= GN_SPLIT)
 };
 constexpr int GN_SPLIT = 64;
+// The same statistics from the per-tile partial sums the producing convolutions left behind (ConvArgs::stats) instead of
+// a pass over the activations: up to two sources (channel concat), each [B][rows][C][2] float32.
+struct GnTileSrc { const float *stats = nullptr; int rows = 0, C = 0; };
+struct GnTileArgs {
+    GnTileSrc src[2];
+    int nsrc = 1, B = 0;
+    long HW = 0;
+    int groups = 0;
+    const float *gamma, *beta;
+    float eps;
+    double *partials;            // [B, groups, GN_SPLIT, 2]
+    float *scale, *shift;        // [B, C1+C2]
+};
+int gn_tiles_launch(const GnTileArgs &a, hipStream_t st);
+// rows of ConvArgs::stats per sample the kernel chosen for this convolution writes (0: that kernel has no fused statistics)
+int conv_stats_rows(const ConvArgs &a);
+int conv_ws_stats_rows(const ConvArgs &a);
+int conv_direct_stats_rows(const ConvArgs &a);
 size_t gn_partials_bytes(int B, int groups);
 int gn_stats_launch(const GnArgs &a, hipStream_t st);
 

@@ -449,6 +449,73 @@ def test_reference_blocks_golden(golden):
         np.testing.assert_allclose(y.cpu().numpy(), g[tag + "_out"], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", [
+    # B, C, H, W, CA, ksA, strideA, resA, act, CB        (conv A's kernel family decides the statistics geometry)
+    (2, 64, 48, 64, 128, 3, 1, True, 2, 64),      # conv_ws 8x32x128 tiles, 16-byte epilogue, residual
+    (2, 64, 40, 36, 64, 3, 1, False, 2, 64),      # conv_ws 16x32x64 tiles, ragged right edge and bottom (masked lanes)
+    (1, 128, 21, 57, 256, 3, 1, True, 2, 40),     # width % 4 != 0: dword epilogue statistics
+    (1, 96, 19, 33, 72, 3, 1, False, 1, 64),      # ragged couts (72 = 64 + 8): partial cout tile, GroupNorm groups 36
+    (2, 64, 33, 47, 64, 3, 2, False, 2, 64),      # stride-2 producer (Downsample)
+    (2, 256, 12, 20, 256, 1, 1, True, 2, 64),     # 1x1 producer with residual (attention proj)
+    (8, 256, 32, 32, 256, 3, 1, True, 2, 64),     # the small-tile variant (4x32x64)
+    (2, 8, 70, 200, 8, 3, 1, True, 2, 8),         # direct narrow kernel 8 -> 8, ragged tiles
+    (1, 16, 37, 130, 16, 3, 1, False, 2, 16),     # direct kernel 16 couts, width % 4 != 0
+    (1, 1, 64, 72, 4, 3, 1, False, 2, 8),         # stem 1 -> 4
+    (2, 16, 30, 44, 4, 1, 1, False, 1, 4),        # narrow 1x1
+    (1, 48, 20, 24, 24, 3, 1, False, 2, 24),      # 16 < couts <= 32: legacy kernel, no fused statistics (falls back)
+])
+def test_fused_groupnorm_statistics_chain(case):
+    """conv A -> GroupNorm(+SiLU) -> conv B where the GroupNorm statistics come from the per-tile partial sums conv A's
+    epilogue wrote (ConvArgs::stats -> gn_tile_reduce -> gn_finalize), for every producing kernel family, against
+    torch ops (fp32): 2e-5 relative like the single-convolution tests."""
+    import ctypes
+    import torch.nn.functional as F
+    from ipdm_pytorch_amd import _lib
+    B, C, H, W, CA, ksA, sA, resA, act, CB = case
+    seed = 3000 + sum(case[:7])
+    x = torch.from_numpy(synth.hash_normal((B, C, H, W), seed)) * 1.3 + 0.2
+    wA = torch.from_numpy(synth.hash_normal((CA, C, ksA, ksA), seed + 1)) / np.sqrt(C * ksA * ksA)
+    bA = torch.from_numpy(synth.hash_normal((CA,), seed + 2))
+    wB = torch.from_numpy(synth.hash_normal((CB, CA, 3, 3), seed + 3)) / np.sqrt(CA * 9)
+    bB = torch.from_numpy(synth.hash_normal((CB,), seed + 4))
+    gamma = torch.from_numpy(synth.hash_uniform((CA,), seed + 5)) + 0.5
+    beta = torch.from_numpy(synth.hash_normal((CA,), seed + 6)) * 0.2
+    groups = ou.gn_groups(CA)
+    mid = F.conv2d(x, wA, bA, stride=sA, padding=ksA // 2)
+    r = torch.from_numpy(synth.hash_normal(tuple(mid.shape), seed + 7)) * 2 - 0.7 if resA else None
+    if resA:
+        mid = mid + r
+    h = F.group_norm(mid, groups, gamma, beta, eps=1e-5)
+    if act == 2:
+        h = F.silu(h)
+    want = F.conv2d(h, wB, bB, padding=1)
+    d_mid = torch.full(tuple(mid.shape), float("nan"), device=DEV)
+    d_out = torch.full(tuple(want.shape), float("nan"), device=DEV)
+    xd = x.to(DEV)
+    rd = r.to(DEV) if resA else None
+    arrs = [np.ascontiguousarray(t.numpy(), dtype=np.float32) for t in (wA, bA, gamma, beta, wB, bB)]
+    rows = ctypes.c_int32(-1)
+    _lib.call("ipdm_op_conv_gn_conv", _lib.ptr(xd), C, B, H, W, _lib.ptr(arrs[0]), _lib.ptr(arrs[1]), CA, ksA, sA, _lib.ptr(rd),
+              groups, _lib.ptr(arrs[2]), _lib.ptr(arrs[3]), act, _lib.ptr(arrs[4]), _lib.ptr(arrs[5]), CB, _lib.ptr(d_mid),
+              _lib.ptr(d_out), ctypes.byref(rows), _lib.current_stream())
+    assert (rows.value > 0) == (not (16 < CA <= 32)), rows.value      # which families fuse: all but the legacy 4-wave kernels
+    assert (d_mid.cpu() - mid).abs().max() <= 2e-5 * max(1.0, mid.abs().max().item())
+    err = (d_out.cpu() - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
+
+
+def test_fused_statistics_equal_activation_pass(monkeypatch):
+    """The two ways of forming GroupNorm statistics (fused per-tile partial sums / IPDM_GN_UNFUSED=1: a pass over the
+    activations) agree to float32 rounding through a whole small UNet, concat inputs and materialised concats included."""
+    net, _ = _native_unet(SMALL_CFGS["b"], 11)
+    x = torch.from_numpy(synth.hash_normal(SMALL_SHAPES["b"], 101)).to(DEV)
+    monkeypatch.delenv("IPDM_GN_UNFUSED", raising=False)
+    a = net(x, 7).cpu()
+    monkeypatch.setenv("IPDM_GN_UNFUSED", "1")
+    b = net(x, 7).cpu()
+    assert (a - b).abs().max() <= 2e-6 and not torch.equal(a, torch.zeros_like(a))
+
+
 def test_lambda_ratio_kernel_body_golden(gd5, golden):
     """ipdm_lambda_ratio against the reference's OWN condition_lambda_ratio_cuda body (misc.npz: executed per simulated
     thread under a stub cuda.grid by tests/golden/make_golden.py) + the host clip [0.05, 0.99] (Model/model.py:558).
