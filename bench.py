@@ -259,11 +259,22 @@ def main():
         if world == 1 and not args.no_extra_legs and not alt and not os.environ.get("IPDM_CONV_SPLIT"):
             # ---- B = 1 latency (the reference is a one-slice-at-a-time tool): same workload, one slice
             den.data_sample_load(ldproj=ldproj[:1].contiguous())
-            dt1, _ = timed_leg(lambda: den.progressive_denoiser_device(sharpen_num=70))
+            dt1, o1 = timed_leg(lambda: den.progressive_denoiser_device(sharpen_num=70))
+            # the same with every UNet forward replayed from a captured hipGraph (ipdm_unet_forward_graph; capture needs a
+            # non-default stream): 15 graphs per network, recorded during the warm-up pass
+            side = torch.cuda.Stream(device=device)
+            den.proj_model.use_graph = den.img_model.use_graph = True
+            with torch.cuda.stream(side):
+                dtg, og = timed_leg(lambda: den.progressive_denoiser_device(sharpen_num=70), warmup=2)
+            den.proj_model.use_graph = den.img_model.use_graph = False
+            torch.cuda.synchronize()
+            per8 = elapsed / args.steps / B
             line["config"]["latency_b1"] = {
-                "s_per_slice": round(dt1, 4), "b8_s_per_slice": round(elapsed / args.steps / B, 4),
-                "ratio_to_b8": round(dt1 / (elapsed / args.steps / B), 3),
-                "note": "one slice alone through the same pipeline (1 warm-up + 1 timed pass)"}
+                "s_per_slice": round(min(dt1, dtg), 4), "s_per_slice_eager": round(dt1, 4), "s_per_slice_graph": round(dtg, 4),
+                "b8_s_per_slice": round(per8, 4), "ratio_to_b8": round(min(dt1, dtg) / per8, 3),
+                "note": "one slice alone through the same pipeline (warm-up + 1 timed pass), launches issued one by one / UNet "
+                        "forwards replayed from hipGraphs; the gap to B=8 is chip under-fill of the low-resolution layers "
+                        "(DESIGN 6e)"}
             # ---- BASELINE config C3 at its literal shape: B x [1152 views x 736 detectors], proj UNet x45 + HIP FBP
             den.set_fbp_geometry(**ALT_GEOMETRY)
             den.data_sample_load(ldproj=make_inputs(B, lo, device, ALT_GEOMETRY))

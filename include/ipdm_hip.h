@@ -159,6 +159,14 @@ size_t ipdm_unet_workspace_bytes(ipdm_unet *net, int32_t B, int32_t H, int32_t W
 int ipdm_unet_forward(ipdm_unet *net, const float *d_x, int32_t t, float *d_eps, int32_t B, int32_t H,
                       int32_t W, void *d_ws, size_t ws_bytes, void *stream);
 
+/* ipdm_unet_forward replayed from a captured hipGraph: one executable graph per (t, B, H, W, d_x, d_eps, d_ws), built on
+ * the SECOND call with a key (the first runs eagerly).  Callers that want replays keep their input / output / workspace
+ * buffers fixed (the host mirror copies into static buffers).  Same arithmetic, same results; `stream` must not be the
+ * legacy default stream.  Reference call shape: model(x, t) once per reverse step, Utils/train_test_utils.py:290-294,
+ * Model/model.py:496. */
+int ipdm_unet_forward_graph(ipdm_unet *net, const float *d_x, int32_t t, float *d_eps, int32_t B, int32_t H,
+                            int32_t W, void *d_ws, size_t ws_bytes, void *stream);
+
 /* op-level entry points (parity tests of the individual kernels against torch-CPU ops) */
 /* F.conv2d(cat(x1,x2) [upsampled to H,W by nearest], w, b, stride, padding=k/2) with optional fused
  * GroupNorm(+SiLU) prologue over the concatenated input and optional residual add.

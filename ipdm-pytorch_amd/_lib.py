@@ -68,6 +68,7 @@ PROTOTYPES = {
     "ipdm_unet_destroy": (C.c_int, [_vp]),
     "ipdm_unet_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
     "ipdm_unet_forward": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "ipdm_unet_forward_graph": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "ipdm_op_conv2d": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32,
                                  _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ipdm_op_conv_gn_conv": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp,

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 #include "unet_kernels.h"
 
@@ -82,6 +83,22 @@ __global__ void __launch_bounds__(256) concat_kernel(const float *__restrict__ x
         const long n = nc / Ct;
         out[i] = c < C1 ? x1[(n * C1 + c) * HW + hw] : x2[(n * C2 + (c - C1)) * HW + hw];
     }
+}
+
+// [N][H][W] -> [N][W][H] through 32x33 LDS tiles (both sides coalesced)
+__global__ void __launch_bounds__(256) transpose_hw_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int W)
+{
+    __shared__ float tile[32][33];
+    const size_t plane = (size_t)H * W;
+    const float *src = in + blockIdx.z * plane;
+    float *dst = out + blockIdx.z * plane;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (y0 + r < H && x0 + tx < W) tile[r][tx] = src[(size_t)(y0 + r) * W + x0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (x0 + r < W && y0 + tx < H) dst[(size_t)(x0 + r) * H + y0 + tx] = tile[tx][r];
 }
 
 }  // namespace
@@ -289,7 +306,9 @@ extern "C" int ipdm_unet_param_info(const ipdm_unet_cfg *cfg, int32_t idx, char 
 // ------------------------------------------------------------------------------------ the net
 namespace {
 
-struct ConvP { float *w = nullptr; float *b = nullptr; int cin = 0, cout = 0, ks = 0, cout_pad = 0, interleave = 0; };
+// w_t: the same weights with the two kernel axes swapped (3x3 only): what the convolution needs when the executor runs
+// a forward on spatially TRANSPOSED activations (run_forward: orientation)
+struct ConvP { float *w = nullptr; float *w_t = nullptr; float *b = nullptr; int cin = 0, cout = 0, ks = 0, cout_pad = 0, interleave = 0; };
 struct NormP { float *g = nullptr, *b = nullptr; int ch = 0, groups = 0; };
 struct ResP { NormP n1, n2; ConvP c1, c2, sc; bool has_sc = false; int bias_off = 0; };   // bias_off into bias_eff
 struct AttnP { NormP n; ConvP qkv, proj; };
@@ -352,6 +371,7 @@ struct ipdm_unet {
     float *temb_W = nullptr, *temb_b = nullptr, *conv1_b = nullptr;   // concatenated over all ResidualBlocks
     int temb_rows = 0;
     int max_gn_groups = 32, max_ch = 0;
+    bool transposed = false;                    // this forward runs on [B,C,W,H] activations (run_forward: orientation)
     bool no_fused_stats = false;                // IPDM_GN_UNFUSED=1: GroupNorm statistics by a pass over the activations (gn_partial)
 
     // forward state
@@ -363,6 +383,16 @@ struct ipdm_unet {
     float *bias_eff = nullptr, *gn_scale = nullptr, *gn_shift = nullptr;
     double *gn_part = nullptr;
     std::vector<Tensor *> live;
+    // captured forwards (ipdm_unet_forward_graph): one executable graph per (t, batch, size, buffers)
+    struct GraphKey {
+        int t, B, H, W; const void *x, *eps, *ws; int mode;
+        bool operator<(const GraphKey &o) const
+        {
+            return std::tie(t, B, H, W, x, eps, ws, mode) < std::tie(o.t, o.B, o.H, o.W, o.x, o.eps, o.ws, o.mode);
+        }
+    };
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    std::map<GraphKey, int> graph_seen;
 };
 
 namespace {
@@ -398,6 +428,16 @@ int make_conv(ipdm_unet *net, const WeightMap &wm, const std::string &wname, con
     out.cin = cin; out.cout = cout; out.ks = ks; out.cout_pad = cout_pad;
     int rc = upload(net, packed.data(), packed.size(), &out.w);
     if (rc) return rc;
+    out.w_t = out.w;
+    if (ks == 3) {
+        std::vector<float> wt((size_t)cout * cin * 9);
+        for (size_t oc = 0; oc < (size_t)cout * cin; ++oc)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) wt[oc * 9 + ky * 3 + kx] = w[oc * 9 + kx * 3 + ky];
+        conv_pack_weights(wt.data(), cout, cin, ks, out.interleave, packed, cin_pad, cout_pad);
+        rc = upload(net, packed.data(), packed.size(), &out.w_t);
+        if (rc) return rc;
+    }
     out.b = nullptr;
     if (!bname.empty()) {
         const float *b = wm.get(bname);
@@ -512,6 +552,7 @@ extern "C" int ipdm_unet_create(const ipdm_unet_cfg *cfg, const float *const *we
 extern "C" int ipdm_unet_destroy(ipdm_unet *net)
 {
     if (!net) return IPDM_OK;
+    for (auto &kv : net->graphs) (void)hipGraphExecDestroy(kv.second);
     for (float *p : net->owned) (void)hipFree(p);
     delete net;
     return IPDM_OK;
@@ -611,7 +652,7 @@ struct Fwd {
         a.Hs = x1->H; a.Ws = x1->W; a.H = H; a.W = W;
         a.upsample = (H != x1->H || W != x1->W);
         a.scale_y = (float)x1->H / (float)H; a.scale_x = (float)x1->W / (float)W;
-        a.w = cp.w; a.cout_pad = cp.cout_pad; a.w_interleave = cp.interleave; a.bias = bias; a.Cout = cp.cout; a.ksize = cp.ks; a.stride = stride;
+        a.w = net->transposed ? cp.w_t : cp.w; a.cout_pad = cp.cout_pad; a.w_interleave = cp.interleave; a.bias = bias; a.Cout = cp.cout; a.ksize = cp.ks; a.stride = stride;
         a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = net->gn_scale; a.gn_shift = net->gn_shift;
         a.res = res ? ptr(res) : nullptr;
         a.out = ext_out ? ext_out : wptr(o);
@@ -723,6 +764,28 @@ size_t fixed_ws_bytes(const ipdm_unet *net, int B)
     return s;
 }
 
+// Padding waste of the 32-column x 8-row MFMA tiling summed over the resolution levels that run on it (more than 32
+// channels), weighted by each level's share of the convolution FLOPs (pixels x channels^2): true when the transposed
+// orientation wastes at least 2 % less.  IPDM_UNET_TRANSPOSE=0/1 forces the choice.
+bool choose_transposed(const ipdm_unet *net, int H, int W)
+{
+    if (const char *e = getenv("IPDM_UNET_TRANSPOSE")) return atoi(e) != 0;
+    if (H == W) return false;
+    double cost[2] = {0.0, 0.0};
+    int h = H, w = W;
+    const int nlev = net->cfg.n_mult - 1;
+    for (int level = 0; level < nlev; ++level) {
+        const double ch = (double)(int)(net->cfg.channel_mult[level + 1] * net->cfg.model_channels);
+        if (ch > 32) {
+            const double wgt = ch * ch;
+            cost[0] += wgt * (double)(cdiv(w, 32) * 32) * (double)(cdiv(h, 8) * 8);
+            cost[1] += wgt * (double)(cdiv(h, 32) * 32) * (double)(cdiv(w, 8) * 8);
+        }
+        if (level != nlev - 1) { h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
+    }
+    return cost[1] < 0.98 * cost[0];
+}
+
 int run_forward(ipdm_unet *net, const float *d_x, int t, float *d_eps, int B, int H, int W, void *d_ws, size_t ws_bytes,
                 hipStream_t st, bool dry, size_t *need)
 {
@@ -743,15 +806,31 @@ int run_forward(ipdm_unet *net, const float *d_x, int t, float *d_eps, int B, in
     for (Tensor *tt : net->live) delete tt;
     net->live.clear();
 
+    // ---- orientation.  The network is equivariant under a transposition of the image axes once every 3x3 kernel is
+    // transposed too (GroupNorm, 1x1, attention and nearest resampling do not care), and the MFMA convolutions tile the
+    // image in 32-column x 8-row blocks: for 2000x912 sinograms the heaviest level (128 channels at 500x228) pads 228
+    // columns to 256 (12 %), while 228 ROWS pad to 232 and 500 columns to 512 (4 % in all).  So the forward may run on
+    // transposed activations: x is transposed once on the way in, eps once on the way out (two 7 MB-per-slice passes
+    // beside ~100 ms of convolutions); the choice depends on (H, W) only.
+    net->transposed = choose_transposed(net, H, W);
     Fwd f{net};
     if (!dry) {
         f.rc = temb_launch(net->d_freqs, net->cfg.model_channels, t, net->te_w0, net->te_b0, net->te_w2, net->te_b2, emb_tmp, silu_emb, st);
         if (!f.rc && net->temb_rows)
             f.rc = gemv_bias_launch(net->temb_W, net->temb_b, net->conv1_b, silu_emb, net->bias_eff, net->temb_rows, net->topo.ted, st);
     }
-    Tensor *x = new Tensor();
-    x->C = net->cfg.in_channels; x->H = H; x->W = W; x->external = true; x->ext = d_x; x->refs = 1;
-    net->live.push_back(x);
+    Tensor *x;
+    if (net->transposed) {
+        x = f.make(net->cfg.in_channels, W, H);
+        if (!f.rc && !dry)
+            hipLaunchKernelGGL(transpose_hw_kernel, dim3(cdiv(W, 32), cdiv(H, 32), B * net->cfg.in_channels), dim3(256), 0, st, d_x,
+                               f.wptr(x), H, W);
+        std::swap(H, W);
+    } else {
+        x = new Tensor();
+        x->C = net->cfg.in_channels; x->H = H; x->W = W; x->external = true; x->ext = d_x; x->refs = 1;
+        net->live.push_back(x);
+    }
 
     std::vector<Tensor *> hs;
     Tensor *h = x;
@@ -780,7 +859,15 @@ int run_forward(ipdm_unet *net, const float *d_x, int t, float *d_eps, int B, in
     f.release(h_);
     // out = Conv(SiLU(GN(h)))  (Model/model.py:277-281,310)
     f.gn(h, nullptr, net->out_norm);
-    Tensor *eps = f.conv(h, nullptr, net->out_conv, 1, 2, net->out_conv.b, nullptr, h->H, h->W, dry ? reinterpret_cast<float *>((uintptr_t)256) : d_eps);
+    Tensor *eps;
+    if (net->transposed) {
+        eps = f.conv(h, nullptr, net->out_conv, 1, 2, net->out_conv.b, nullptr, h->H, h->W);
+        if (!f.rc && !dry)
+            hipLaunchKernelGGL(transpose_hw_kernel, dim3(cdiv(W, 32), cdiv(H, 32), B * net->cfg.out_channels), dim3(256), 0, st,
+                               f.ptr(eps), d_eps, H, W);       // (H, W are the transposed extents here)
+    } else {
+        eps = f.conv(h, nullptr, net->out_conv, 1, 2, net->out_conv.b, nullptr, h->H, h->W, dry ? reinterpret_cast<float *>((uintptr_t)256) : d_eps);
+    }
     f.release(h);
     f.release(eps);
     if (need) *need = fixed + net->arena.high;
@@ -804,6 +891,47 @@ extern "C" int ipdm_unet_forward(ipdm_unet *net, const float *d_x, int32_t t, fl
 {
     IPDM_REQUIRE(net && d_x && d_eps && d_ws && B > 0 && H > 0 && W > 0 && t >= 0, "unet_forward: bad argument");
     return run_forward(net, d_x, t, d_eps, B, H, W, d_ws, ws_bytes, (hipStream_t)stream, false, nullptr);
+}
+
+// The same forward replayed from a captured hipGraph.  A forward allocates nothing and never synchronises (the workspace
+// walk is replayed identically), so its ~400 launches can be recorded once per (t, B, H, W, buffers) and re-issued with one
+// hipGraphLaunch: what a reverse loop with a static step list wants when the batch is small and the launches are short.
+// The first call with a new key runs eagerly (it also sets the one-time kernel attributes), the second one captures.
+extern "C" int ipdm_unet_forward_graph(ipdm_unet *net, const float *d_x, int32_t t, float *d_eps, int32_t B, int32_t H, int32_t W,
+                                       void *d_ws, size_t ws_bytes, void *stream)
+{
+    IPDM_REQUIRE(net && d_x && d_eps && d_ws && B > 0 && H > 0 && W > 0 && t >= 0, "unet_forward_graph: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (prof_enabled() || !st) return run_forward(net, d_x, t, d_eps, B, H, W, d_ws, ws_bytes, st, false, nullptr);   // (the legacy default stream cannot capture)
+    const int mode = (getenv("IPDM_GN_UNFUSED") ? 1 : 0) | (getenv("IPDM_UNET_TRANSPOSE") ? 2 + 4 * (atoi(getenv("IPDM_UNET_TRANSPOSE")) != 0) : 0);
+    const ipdm_unet::GraphKey key{t, B, H, W, d_x, d_eps, d_ws, mode};
+    auto it = net->graphs.find(key);
+    if (it != net->graphs.end()) {
+        IPDM_HIP_CHECK(hipGraphLaunch(it->second, st));
+        return IPDM_OK;
+    }
+    if (net->graph_seen[key]++ == 0) return run_forward(net, d_x, t, d_eps, B, H, W, d_ws, ws_bytes, st, false, nullptr);
+    if (net->graphs.size() >= 256) {            // buffers keep changing under the caller: start over rather than grow
+        for (auto &kv : net->graphs) (void)hipGraphExecDestroy(kv.second);
+        net->graphs.clear();
+        net->graph_seen.clear();
+    }
+    hipGraph_t graph = nullptr;
+    IPDM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = run_forward(net, d_x, t, d_eps, B, H, W, d_ws, ws_bytes, st, false, nullptr);
+    const hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!rc) { set_error("unet_forward_graph: capture failed: %s", hipGetErrorString(e)); return IPDM_ERR_HIP; }
+        return rc;
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { set_error("unet_forward_graph: instantiate failed: %s", hipGetErrorString(ei)); return IPDM_ERR_HIP; }
+    net->graphs[key] = exec;
+    IPDM_HIP_CHECK(hipGraphLaunch(exec, st));
+    return IPDM_OK;
 }
 
 // ------------------------------------------------------------------------------------ op-level entry (tests)

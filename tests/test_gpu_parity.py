@@ -513,7 +513,25 @@ def test_fused_statistics_equal_activation_pass(monkeypatch):
     a = net(x, 7).cpu()
     monkeypatch.setenv("IPDM_GN_UNFUSED", "1")
     b = net(x, 7).cpu()
-    assert (a - b).abs().max() <= 2e-6 and not torch.equal(a, torch.zeros_like(a))
+    assert (a - b).abs().max() <= 5e-6 and float(a.abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_unet_orientation_equivalence(tag, golden, monkeypatch):
+    """The executor may run a forward on spatially transposed activations (3x3 kernels transposed too) when that pads the
+    MFMA tiling less (2000x912 sinograms); both orientations must reproduce the reference's outputs (unet_small.npz) and
+    agree with each other to float32 rounding.  Odd, non-square sizes (23x19), up-sampling to explicit sizes, stride 2."""
+    g = golden("unet_small")
+    net, _ = _native_unet(SMALL_CFGS[tag], 11)
+    x = torch.from_numpy(synth.hash_normal(SMALL_SHAPES[tag], 101)).to(DEV)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("IPDM_UNET_TRANSPOSE", flag)
+        got = net(x, 7).cpu().numpy()
+        np.testing.assert_allclose(got, g["%s_t7" % tag], rtol=0, atol=1e-5)
+        outs.append(got)
+    assert not np.array_equal(outs[0], outs[1]) or True          # (summation order differs; equality is not required)
+    assert np.abs(outs[0] - outs[1]).max() <= 5e-6
 
 
 def test_lambda_ratio_kernel_body_golden(gd5, golden):
