@@ -218,9 +218,11 @@ int ipdm_art_plan_destroy(ipdm_art_plan *plan);
 size_t ipdm_art_workspace_bytes(const ipdm_art_plan *plan, int32_t B);
 /* recons_torch(h_proj, lut_area, betas, nstart, ntv, sample_rate, permute): d_proj [B, na, nr] -> d_volume [B, ny, nx]
  * (NOT permuted: the caller applies permute(0,2,1) as a view, PyAPI.cpp:55-57).  sample_rate > 1 uses the first
- * na / sample_rate views and rows, as the reference does (PyAPI.cpp:37).  Asynchronous on `stream`; the whole
- * reconstruction (nsart sweeps of one launch per view + the NSL0-TV steps, all scalars kept on the device) issues no
- * host synchronisation. */
+ * na / sample_rate views and rows, as the reference does (PyAPI.cpp:37).  Every launch is on `stream` and all scalars
+ * (dp, dg, alpha) stay on the device.  With one launch per view the call returns without synchronising; when a sweep
+ * is ONE launch (the sweep's grid fits on the device, checked at plan creation) the call ends with one stream
+ * synchronisation that reads whether a sweep's grid barrier expired (device shared with other work) -- such a
+ * reconstruction is redone with one launch per view before the call returns, never handed back as success. */
 int ipdm_art_reconstruct(ipdm_art_plan *plan, const float *d_proj, float *d_volume, int32_t B, int32_t nsart,
                          int32_t ntv, int32_t sample_rate, void *d_ws, size_t ws_bytes, void *stream);
 /* proj_torch(h_volume, lut_area, betas): d_volume [B, ny, nx] -> d_proj [B, na, nr] */

@@ -618,7 +618,14 @@ struct ipdm_art_plan {
     float4 *d_lines = nullptr;
     ArtView *d_views = nullptr;
     bool persistent_ok = false;     // the 16x16-tile grid of one sweep is co-resident on this device
+    unsigned int *d_abort = nullptr;    // sticky: some one-launch sweep of the running reconstruction gave up on its grid barrier
 };
+
+// after every one-launch sweep: remember an expired grid barrier (sync[0]) past the next sweep's reset of `sync`
+__global__ void art_abort_latch_kernel(const unsigned int *sync, unsigned int *latch)
+{
+    if (sync[0]) *latch = 1u;
+}
 
 static int project_bins(ipdm_art_plan *p, const float *d_vol, unsigned long long *bins, int na, int B, hipStream_t st)
 {
@@ -666,6 +673,7 @@ extern "C" int ipdm_art_plan_create(const ipdm_art_geom *g, const float *lut, co
     IPDM_HIP_CHECK(hipMalloc((void **)&p->d_views, views.size() * sizeof(ArtView)));
     IPDM_HIP_CHECK(hipMalloc((void **)&p->d_lines, (size_t)g->na * (g->nr + 1) * sizeof(float4)));
     IPDM_HIP_CHECK(hipMalloc((void **)&p->d_norm, norm_n * sizeof(float)));
+    IPDM_HIP_CHECK(hipMalloc((void **)&p->d_abort, sizeof(unsigned int)));
     IPDM_HIP_CHECK(hipMemcpy(p->d_lut, lut, lut_n * sizeof(float), hipMemcpyHostToDevice));
     IPDM_HIP_CHECK(hipMemcpy(p->d_views, views.data(), views.size() * sizeof(ArtView), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(art_lines_kernel, dim3(cdiv(g->nr + 1, 256), g->na), dim3(256), 0, nullptr, c, p->d_views,
@@ -700,6 +708,7 @@ extern "C" int ipdm_art_plan_destroy(ipdm_art_plan *p)
     (void)hipFree(p->d_views);
     (void)hipFree(p->d_lines);
     (void)hipFree(p->d_norm);
+    (void)hipFree(p->d_abort);
     delete p;
     return IPDM_OK;
 }
@@ -763,6 +772,8 @@ extern "C" int ipdm_art_reconstruct(ipdm_art_plan *p, const float *d_proj, float
     // the sparse flush atomics and correction-window fills for the same pixels)
     constexpr int TS = 16;
     const dim3 stiles(cdiv(c.nx, TS), cdiv(c.ny, TS)), sblk(TS, TS);
+    const bool one_launch = p->persistent_ok && nsart > 0;
+    if (one_launch) IPDM_HIP_CHECK(hipMemsetAsync(p->d_abort, 0, sizeof(unsigned int), st));
     for (int b0 = 0; b0 < B; b0 += BMAX) {
         const int nb = B - b0 < BMAX ? B - b0 : BMAX;
         ArtWs w = carve(p, d_ws, nb);
@@ -780,6 +791,7 @@ extern "C" int ipdm_art_reconstruct(ipdm_art_plan *p, const float *d_proj, float
                 PersistArgs pa{c, p->d_lut, p->d_lines, p->d_views, p->d_norm, d_proj + b0 * proj_stride, proj_stride,
                                w.x_for, w.bins, w.sync, na, nb, lamda};
                 hipLaunchKernelGGL(art_sweep_persistent_kernel, tiles, blk, 0, st, pa);
+                hipLaunchKernelGGL(art_abort_latch_kernel, dim3(1), dim3(1), 0, st, w.sync, p->d_abort);
                 IPDM_LAUNCH_CHECK();
             } else {
             SweepArgs a{c, p->d_lut, p->d_lines, p->d_views, p->d_norm, d_proj + b0 * proj_stride, proj_stride,
@@ -810,6 +822,19 @@ extern "C" int ipdm_art_reconstruct(ipdm_art_plan *p, const float *d_proj, float
             hipLaunchKernelGGL(art_state_update_kernel, dim3(nb), dim3(1), 0, st, w.state, w.partial, SQ_BLOCKS, 2);
             lamda = (float)(lamda * 0.95);           // .cu:951
             IPDM_LAUNCH_CHECK();
+        }
+    }
+    if (one_launch) {
+        // The hand-written grid barrier of the one-launch sweep needs its whole grid resident; residency was checked on an
+        // idle device at plan creation, but other work on the device (another stream, another process) can break it.  An
+        // expired barrier poisons the volume with NaN; never hand that back as success: this path ends with ONE stream
+        // synchronisation, and a reconstruction that gave up is redone with one launch per view (and the plan stays there).
+        unsigned int aborted = 0;
+        IPDM_HIP_CHECK(hipMemcpyAsync(&aborted, p->d_abort, sizeof(aborted), hipMemcpyDeviceToHost, st));
+        IPDM_HIP_CHECK(hipStreamSynchronize(st));
+        if (aborted) {
+            p->persistent_ok = false;
+            return ipdm_art_reconstruct(p, d_proj, d_volume, B, nsart, ntv, sample_rate, d_ws, ws_bytes, stream);
         }
     }
     return IPDM_OK;

@@ -364,6 +364,17 @@ int conv_stats_rows(const ConvArgs &a)
     return 0;                                                           // legacy 4-wave kernels
 }
 
+int conv_split(const ConvArgs &a)
+{
+    if (conv_sx_pieces(a.w_interleave) || !a.w_interleave) return 1;
+    return conv_ws_split(a);
+}
+size_t conv_split_ws_bytes(const ConvArgs &a)
+{
+    const int S = conv_split(a);
+    return S > 1 ? (size_t)S * a.B * a.Cout * a.Ho * a.Wo * sizeof(float) : 0;
+}
+
 int conv_k_chunk() { return 8; }
 int conv_ws_k_chunk(int ks, int interleave) { return conv_sx_pieces(interleave) ? 16 : ((interleave && ks == 1) ? 32 : 8); }
 

@@ -71,7 +71,7 @@ struct WsTile {
     static constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(float);
 };
 
-struct TileId { int n, oy0, ox0, co0; };
+struct TileId { int n, oy0, ox0, co0, ks; };      // ks: which slice of the K (input channel) range, ConvArgs::ksplit
 
 template <int TH, int TW, int BN>
 __device__ inline TileId decode_tile(const ConvArgs &a, int tile)
@@ -82,7 +82,9 @@ __device__ inline TileId decode_tile(const ConvArgs &a, int tile)
     const int tx = rest % a.tiles_x;
     rest /= a.tiles_x;
     const int ty = rest % a.tiles_y;
-    t.n = rest / a.tiles_y;
+    rest /= a.tiles_y;
+    t.n = rest % a.B;
+    t.ks = rest / a.B;
     t.oy0 = ty * TH;
     t.ox0 = tx * TW;
     t.co0 = co_t * BN;
@@ -148,7 +150,10 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     auto tile_of = [&](int k) { return k * G + (local + 5 * k) % G; };
     const int n_my = rounds == 0 ? 0 : (tile_of(rounds - 1) < ntiles ? rounds : rounds - 1);
     const int Ctot = a.C1 + a.C2;
-    const int nchunks = (Ctot + KC - 1) / KC;
+    // K split (ConvArgs::ksplit > 1: layers with too few tiles to fill the chip): a "tile" of the schedule is then one
+    // slice of the channel chunks of an output tile, and its sums go to slice ks of a partial buffer (no bias, residual
+    // or statistics here: splitk_combine adds the slices in a fixed order and applies them)
+    const int nchunks = (Ctot + KC - 1) / KC / a.ksplit;
     const int S = n_my * nchunks;                  // chunks in this workgroup's stream
     const int plane_bytes = a.Hs * a.Ws * 4;
     if (threadIdx.x >= 256) {
@@ -193,7 +198,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                         in_voff[j] = in_ok[j] ? (sy * a.Ws + sx) * 4 : OOB;      // padding / idle slots read 0
                     }
                 }
-                const int c0 = ch * KC;
+                const int c0 = (t.ks * nchunks + ch) * KC;
                 const int nvalid = min(KC, Ctot - c0);
                 float *ib = lds + (s & 1) * T::BUF;
                 // a chunk never straddles the two concatenated sources (launcher: C1 % KC == 0 when C2 > 0)
@@ -388,7 +393,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
             // ---- tile epilogue: (+ residual) -> NCHW stores, 32 consecutive pixels per half-wave; the stores drain
             //      while the next tile is multiplied
             const TileId t = decode_tile<T::TH, T::TW, T::BN>(a, tile_of(k));
-            const size_t sample = (size_t)t.n * a.Cout * out_plane;
+            const size_t sample = ((size_t)t.ks * a.B + t.n) * a.Cout * out_plane;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * out_plane * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0, a.Cout * out_plane * 4, 0x00020000);
             // per-lane offset: lane part, or out of range for columns beyond Wo / rows beyond Ho (dropped by the range
@@ -583,7 +588,10 @@ int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
                      (long)a.Cout * a.Ho * a.Wo < (1L << 29) &&
                      (long)((a.C1 + a.C2 + KC - 1) / KC * KC) * T::TAPS * a.cout_pad < (1L << 29),
                  "conv2d: per-sample tensor exceeds the 2 GiB buffer-addressing range");
-    const long ntiles = (long)a.tiles_x * a.tiles_y * a.co_tiles * a.B;
+    if (a.ksplit < 1) a.ksplit = 1;
+    IPDM_REQUIRE(((a.C1 + a.C2 + KC - 1) / KC) % a.ksplit == 0 && (a.ksplit == 1 || (!a.bias && !a.res && !a.stats)),
+                 "conv2d: bad K split %d", a.ksplit);
+    const long ntiles = (long)a.tiles_x * a.tiles_y * a.co_tiles * a.B * a.ksplit;
     IPDM_REQUIRE(ntiles < (1L << 31), "conv2d: too many tiles");
     const int cus = num_cus();
     int G = (int)(ntiles < cus ? ntiles : cus);
@@ -624,11 +632,93 @@ static int ws_tile_rows(const ConvArgs &a)
     return 8;
 }
 
-int conv_ws_stats_rows(const ConvArgs &a) { return cdiv(a.Ho, ws_tile_rows(a)) * cdiv(a.Wo, 32) * 4; }
+// ---- K split: which layers, how many slices
+static int ws_tile_couts(const ConvArgs &a)
+{
+    if (a.w_interleave == 4) {
+        if (a.ksize == 3 && a.stride == 1) {
+            const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128) * a.B;
+            return tiles < 160 ? 64 : 128;
+        }
+        return 128;
+    }
+    return 64;
+}
+
+int conv_ws_split(const ConvArgs &a)
+{
+    static const bool off = getenv("IPDM_CONV_NO_SPLITK") != nullptr;
+    if (off || !a.w_interleave || a.w_interleave > 4) return 1;
+    const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, ws_tile_rows(a)) * cdiv(a.Cout, ws_tile_couts(a)) * a.B;
+    if (tiles >= 128) return 1;                     // at least half of the chip is busy already
+    const int nch = cdiv(a.C1 + a.C2, a.ksize == 1 ? 32 : 8);
+    int best = 1;
+    for (int S = 2; S <= 8; ++S)
+        if (nch % S == 0 && nch / S >= 2 && tiles * S <= 256) best = S;
+    return best;
+}
+
+int conv_ws_stats_rows(const ConvArgs &a)
+{
+    if (a.split_ws && conv_ws_split(a) > 1) return cdiv((long)a.Ho * a.Wo, SPLIT_PIX);
+    return cdiv(a.Ho, ws_tile_rows(a)) * cdiv(a.Wo, 32) * 4;
+}
+
+namespace {
+// out = sum over the K slices (ascending: a fixed order) + bias (+ residual); the GroupNorm statistics of the result as
+// one row of per-channel partial sums per SPLIT_PIX pixels.  Block = (pixel chunk, cout, sample).
+__global__ void __launch_bounds__(256) splitk_combine_kernel(const float *__restrict__ ws, int S, const float *__restrict__ bias,
+                                                             const float *__restrict__ res, float *__restrict__ out,
+                                                             float *__restrict__ stats, int rows, int B, int Cout, int HW)
+{
+    const int p = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+    const size_t plane = ((size_t)n * Cout + c) * HW, slice = (size_t)B * Cout * HW;
+    const float b = bias ? bias[c] : 0.0f;
+    float s1 = 0.0f, s2 = 0.0f;
+    const int end = min(HW, (p + 1) * SPLIT_PIX);
+    for (int i = p * SPLIT_PIX + threadIdx.x; i < end; i += 256) {
+        float v = ws[plane + i];
+        for (int s = 1; s < S; ++s) v += ws[(size_t)s * slice + plane + i];
+        v += b;                                     // conv, then bias, then the residual: the order of the unsplit kernels
+        if (res) v += res[plane + i];
+        out[plane + i] = v;
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+    }
+    if (!stats) return;
+    __shared__ float r1[4], r2[4];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float *d = stats + (((size_t)n * rows + p) * Cout + c) * 2;
+        d[0] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+        d[1] = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+    }
+}
+}  // namespace
+
+static int conv2d_ws_dispatch(const ConvArgs &a, hipStream_t st);
 
 // 3x3 stride-1 convolutions with more than 32 output channels (weights packed cout-interleaved, see
 // conv_weight_interleave / conv_pack_weights).
 int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
+{
+    const int S = a.split_ws ? conv_ws_split(a) : 1;
+    if (S == 1) return conv2d_ws_dispatch(a, st);
+    ConvArgs k = a;
+    k.out = a.split_ws; k.bias = nullptr; k.res = nullptr; k.stats = nullptr; k.stats_rows = 0; k.ksplit = S;
+    if (int rc = conv2d_ws_dispatch(k, st)) return rc;
+    const int HW = a.Ho * a.Wo, rows = cdiv(HW, SPLIT_PIX);
+    IPDM_REQUIRE(!a.stats || a.stats_rows == rows, "conv2d: statistics rows %d != %d (K split)", a.stats_rows, rows);
+    hipLaunchKernelGGL(splitk_combine_kernel, dim3(rows, a.Cout, a.B), dim3(256), 0, st, a.split_ws, S, a.bias, a.res, a.out,
+                       a.stats, rows, a.B, a.Cout, HW);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+static int conv2d_ws_dispatch(const ConvArgs &a, hipStream_t st)
 {
     if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 4) {
         // layers whose 8x32x128 tiling gives fewer tiles than CUs (32x32 and 63x29 at 256 channels) use 4x32x64 tiles

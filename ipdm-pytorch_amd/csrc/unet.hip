@@ -635,6 +635,16 @@ struct Fwd {
         // (shape fields first: the statistics geometry depends on the kernel the dispatcher picks, in dry runs too)
         a.C1 = x1->C; a.C2 = x2 ? x2->C : 0; a.B = net->B; a.Cout = cp.cout; a.ksize = cp.ks; a.stride = stride; a.Ho = Ho; a.Wo = Wo;
         a.w_interleave = cp.interleave; a.cout_pad = cp.cout_pad;
+        // layers with too few tiles to fill the chip are split along K into a scratch buffer (conv_ws.hip)
+        const size_t split_bytes = conv_split_ws_bytes(a);
+        size_t split_off = (size_t)-1;
+        if (split_bytes) {
+            split_off = net->arena.alloc(split_bytes);
+            if (split_off == (size_t)-1) { set_error("unet_forward: workspace exhausted"); rc = IPDM_ERR_WORKSPACE; split_off = 0; }
+            a.split_ws = (float *)(net->ws + split_off);
+            if (!a.split_ws) a.split_ws = reinterpret_cast<float *>((uintptr_t)256);
+        }
+        struct SplitGuard { Arena &ar; size_t off, bytes; ~SplitGuard() { if (off != (size_t)-1) ar.release(off, bytes); } } split_guard{net->arena, split_off, split_bytes};
         if (want_stats && !ext_out && !net->no_fused_stats) {
             const int rows = conv_stats_rows(a);
             if (rows > 0) {
@@ -947,7 +957,7 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
     int cin_pad, cout_pad;
     const int interleave = conv_weight_interleave(Cout, ksize, stride);
     conv_pack_weights(w_host, Cout, Cin, ksize, interleave, packed, cin_pad, cout_pad);
-    float *d_w = nullptr, *d_b = nullptr, *d_g = nullptr, *d_be = nullptr, *d_sc = nullptr, *d_sh = nullptr;
+    float *d_w = nullptr, *d_b = nullptr, *d_g = nullptr, *d_be = nullptr, *d_sc = nullptr, *d_sh = nullptr, *d_split = nullptr;
     double *d_part = nullptr;
     IPDM_HIP_CHECK(hipMalloc((void **)&d_w, packed.size() * sizeof(float)));
     IPDM_HIP_CHECK(hipMemcpy(d_w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -980,9 +990,12 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
         a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
         a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
         a.tiles_x = a.tiles_y = a.co_tiles = 0;
+        if (conv_split_ws_bytes(a)) IPDM_HIP_CHECK(hipMalloc((void **)&d_split, conv_split_ws_bytes(a)));
+        a.split_ws = d_split;
         rc = conv2d_launch(a, st);
     }
     IPDM_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(d_split);
     (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_g); (void)hipFree(d_be); (void)hipFree(d_sc); (void)hipFree(d_sh);
     (void)hipFree(d_part);
     return rc;
@@ -1030,6 +1043,7 @@ extern "C" int ipdm_op_conv_gn_conv(const float *d_x, int32_t C, int32_t B, int3
     a.scale_y = a.scale_x = 1.f; a.w = d_wA; a.cout_pad = coutpA; a.w_interleave = ilA; a.bias = d_bA; a.Cout = CA; a.ksize = ksA;
     a.stride = strideA; a.Ho = Hm; a.Wo = Wm; a.act = 0; a.gn_scale = a.gn_shift = nullptr; a.res = d_resA; a.out = d_mid;
     a.tiles_x = a.tiles_y = a.co_tiles = 0;
+    if (!rc && conv_split_ws_bytes(a)) { float *d_sp; rc = dev(nullptr, conv_split_ws_bytes(a), (void **)&d_sp); if (!rc) a.split_ws = d_sp; }
     const int rows = conv_stats_rows(a);
     if (fused_rows) *fused_rows = rows;
     if (!rc && rows > 0) {
@@ -1094,6 +1108,9 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     a.scale_y = a.scale_x = 1.f; a.w = d_w; a.cout_pad = cout_pad; a.w_interleave = interleave; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
     a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
     a.tiles_x = a.tiles_y = a.co_tiles = 0;
+    float *d_split = nullptr;
+    if (conv_split_ws_bytes(a)) IPDM_HIP_CHECK(hipMalloc((void **)&d_split, conv_split_ws_bytes(a)));
+    a.split_ws = d_split;
     int rc = 0;
     const bool stamps = getenv("IPDM_CONV_DBG") && (atoi(getenv("IPDM_CONV_DBG")) & 8);
     if (stamps) { IPDM_HIP_CHECK(hipMalloc((void **)&a.dbg_buf, 4096 * 8 * 8)); IPDM_HIP_CHECK(hipMemset(a.dbg_buf, 0, 4096 * 8 * 8)); }
@@ -1118,6 +1135,7 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
                         s4[4] / nz, s4[5] / nz, s4[6] / nz, s4[7] / nz);
         (void)hipFree(a.dbg_buf);
     }
+    (void)hipFree(d_split);
     (void)hipFree(d_w); (void)hipFree(d_x1); (void)hipFree(d_x2); (void)hipFree(d_out); (void)hipFree(d_res); (void)hipFree(d_sc);
     (void)hipFree(d_sh); (void)hipFree(d_b); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;

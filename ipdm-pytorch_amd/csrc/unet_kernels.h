@@ -29,6 +29,12 @@ struct ConvArgs {
     // hundred pixels; combined in float64 by gn_tiles_launch).  stats_rows = conv_stats_rows(args).
     float *stats = nullptr;
     int stats_rows = 0;
+    // K split of layers with too few output tiles to fill the chip (batch 1, low resolutions): conv_split(args) slices of
+    // the input-channel range are summed by separate workgroups into split_ws [ksplit][B,Cout,Ho,Wo] (caller-provided,
+    // conv_split_ws_bytes(args) bytes) and a combine pass adds them in a fixed order (+ bias, residual, statistics).
+    // ksplit is set by the launcher; callers only provide split_ws (null: never split).
+    float *split_ws = nullptr;
+    int ksplit = 1;
     int dbg = 0;                        // IPDM_CONV_DBG bit mask (kernel experiments only; 0 on the product path)
     unsigned long long *dbg_buf = nullptr;   // dbg & 8: per-workgroup cycle stamps [grid][4]
 };
@@ -84,7 +90,11 @@ struct GnTileArgs {
 int gn_tiles_launch(const GnTileArgs &a, hipStream_t st);
 // rows of ConvArgs::stats per sample the kernel chosen for this convolution writes (0: that kernel has no fused statistics)
 int conv_stats_rows(const ConvArgs &a);
+int conv_split(const ConvArgs &a);                 // K slices the launcher would use given a split workspace (1: no split)
+size_t conv_split_ws_bytes(const ConvArgs &a);     // 0 when conv_split(a) == 1
+constexpr int SPLIT_PIX = 2048;                    // pixels per workgroup (= per statistics row) of the combine pass
 int conv_ws_stats_rows(const ConvArgs &a);
+int conv_ws_split(const ConvArgs &a);
 int conv_direct_stats_rows(const ConvArgs &a);
 size_t gn_partials_bytes(int B, int groups);
 int gn_stats_launch(const GnArgs &a, hipStream_t st);

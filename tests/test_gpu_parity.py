@@ -303,6 +303,11 @@ def _conv_case(B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res, seed):
     (1, 144, 0, 24, 40, 24, 40, 16, 3, 1, 2, False),        # 144 -> 16 up-block conv (direct kernel, 18 channel chunks)
     (8, 128, 0, 64, 96, 64, 96, 128, 3, 1, 2, True),        # enough tiles for the 8x32x128 persistent schedule (several rounds)
     (2, 64, 64, 48, 40, 48, 40, 64, 3, 1, 2, True),         # 16x32x64 tiles, concat, ragged right edge
+    (1, 256, 0, 32, 32, 32, 32, 256, 3, 1, 2, True),        # batch 1, 32 tiles: K split into 8 slices + combine (bias, residual)
+    (1, 256, 256, 16, 24, 16, 24, 256, 3, 1, 2, False),     # K split over a concat input
+    (1, 256, 0, 16, 16, 16, 16, 768, 1, 1, 1, False),       # 1x1 (qkv) with GN, K split into 4
+    (1, 256, 0, 31, 45, 31, 45, 256, 3, 2, 0, False),       # stride 2, K split
+    (1, 192, 0, 29, 63, 29, 63, 72, 3, 1, 2, True),         # K split with ragged couts and width % 4 != 0
 ])
 def test_conv_kernel(case):
     _conv_case(*case, seed=200 + sum(case[:8]))
@@ -458,6 +463,8 @@ def test_reference_blocks_golden(golden):
     (2, 64, 33, 47, 64, 3, 2, False, 2, 64),      # stride-2 producer (Downsample)
     (2, 256, 12, 20, 256, 1, 1, True, 2, 64),     # 1x1 producer with residual (attention proj)
     (8, 256, 32, 32, 256, 3, 1, True, 2, 64),     # the small-tile variant (4x32x64)
+    (1, 256, 32, 32, 256, 3, 1, True, 2, 64),     # batch 1: K split, statistics from the combine pass
+    (1, 256, 24, 40, 256, 1, 1, True, 2, 64),     # 1x1 producer, K split
     (2, 8, 70, 200, 8, 3, 1, True, 2, 8),         # direct narrow kernel 8 -> 8, ragged tiles
     (1, 16, 37, 130, 16, 3, 1, False, 2, 16),     # direct kernel 16 couts, width % 4 != 0
     (1, 1, 64, 72, 4, 3, 1, False, 2, 8),         # stem 1 -> 4
@@ -978,7 +985,8 @@ def test_full_size_pipeline_psnr():
                                    lambda: next(draws), sharpen_num=70)
     want = want.numpy()
     assert got.shape == want.shape == (1, 1, 512, 512)
-    assert np.abs(got - want).max() <= 5e-4 * max(1.0, np.abs(want).max())
+    err = float(np.abs(got - want).max())
+    assert err <= 2e-4 * max(1.0, float(np.abs(want).max())), err      # end to end <= 2e-4 relative max-abs
     truth = od.miu2pixel(torch.from_numpy(synth.rasterize(synth.ellipse_phantom(4)))).numpy()
     p_hip = od.psnr(truth, od.miu2pixel(torch.from_numpy(got[0, 0])).numpy())
     p_cpu = od.psnr(truth, od.miu2pixel(torch.from_numpy(want[0, 0])).numpy())
