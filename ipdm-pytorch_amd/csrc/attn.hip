@@ -183,8 +183,10 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
 // The only producer VALU is the 16 multiplies of K by the scale per tile (they fit the MFMA wave's stall gaps).
 template <int D, int QT>
 __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restrict__ qkv, float *__restrict__ out,
-                                                           int heads, int T, float scale)
+                                                           int heads, int T, float scale, int zsplit, float *__restrict__ part)
 {
+    // zsplit > 1 (few queries: batch 1, low resolutions): blockIdx.z takes a slice of the key tiles and leaves its
+    // UNNORMALISED output, running maximum and sum in `part`; attention_combine_kernel merges the slices
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STAGE = KV * KP + D * VP;
     const int bh = blockIdx.y;                      // sample*heads + head
@@ -193,11 +195,13 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
     const float *kp = qp + (size_t)D * T;
     const float *vp = qp + (size_t)2 * D * T;
     const int ntiles = (T + KV - 1) / KV;
+    const int tps = (ntiles + zsplit - 1) / zsplit;
+    const int it0 = blockIdx.z * tps, it1 = min(ntiles, it0 + tps);
 
     if (threadIdx.x >= 256) {
         // ------------------------------------------------------------------ producers
         const int tid = threadIdx.x - 256;
-        for (int it = 0; it < ntiles; ++it) {
+        for (int it = it0; it < it1; ++it) {
             const int s0 = it * KV;
             float *k_lds = smem + (it & 1) * STAGE, *v_lds = k_lds + KV * KP;
             float kr[(D * KV) / 256], vr[(D * KV) / 256];
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.0f; }
 
-    for (int it = 0; it < ntiles; ++it) {
+    for (int it = it0; it < it1; ++it) {
         const int s0 = it * KV;
         __syncthreads();                           // hand-over: stage (it&1) is complete
         const float *k_lds = smem + (it & 1) * STAGE, *v_lds = k_lds + KV * KP;
@@ -315,6 +319,21 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
             }
         }
     }
+    if (zsplit > 1) {
+        float *pp = part + ((size_t)blockIdx.z * gridDim.y + bh) * (D + 2) * T;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int t = t0 + qt * 32 + l31;
+            if (t < T) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pp[(size_t)(cb * 32 + crow(r, lh)) * T + t] = o[qt][cb][r];
+                if (lh == 0) { pp[(size_t)D * T + t] = m_run[qt]; pp[(size_t)(D + 1) * T + t] = l_run[qt]; }
+            }
+        }
+        return;
+    }
     float *op = out + ((size_t)b * heads * D + (size_t)head * D) * T;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -332,11 +351,56 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
     }
 }
 
+// merges the key slices of a split launch: out = sum_z w_z o_z / sum_z w_z l_z, w_z = exp(m_z - max m)
+template <int D>
+__global__ void __launch_bounds__(256) attention_combine_kernel(const float *__restrict__ part, float *__restrict__ out, int T, int Z)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, bh = blockIdx.y;
+    if (t >= T) return;
+    const size_t slice = (size_t)gridDim.y * (D + 2) * T;
+    const float *p = part + (size_t)bh * (D + 2) * T;
+    float m = -INFINITY;
+    for (int z = 0; z < Z; ++z) m = fmaxf(m, p[z * slice + (size_t)D * T + t]);
+    float w[8], L = 0.0f;
+    for (int z = 0; z < Z; ++z) {
+        w[z] = __builtin_amdgcn_exp2f((p[z * slice + (size_t)D * T + t] - m) * LOG2E);      // an empty slice has m = -inf: weight 0
+        L = fmaf(w[z], p[z * slice + (size_t)(D + 1) * T + t], L);
+    }
+    const float inv = 1.0f / L;
+    for (int c = 0; c < D; ++c) {
+        float acc = 0.0f;
+        for (int z = 0; z < Z; ++z) acc = fmaf(w[z], p[z * slice + (size_t)c * T + t], acc);
+        out[((size_t)bh * D + c) * T + t] = acc * inv;
+    }
+}
+
+// Key slices of the wave-specialised kernel.  Like the K split of the convolutions the count depends on the layer alone
+// (T and the head count, never the batch size), so that a slice of a batch stays bit-equal to the slice sampled alone:
+// only sequences that cannot fill the chip even at 8 slices per GPU are split (at most 64 query workgroups per sample).
+int attention_kv_split(int B, int heads, int d, int T)
+{
+    static const bool off = getenv("IPDM_ATTN_NO_KVSPLIT") != nullptr;
+    (void)B;
+    if (off || d != 64) return 1;
+    const long wg = (long)cdiv(T, 128) * heads;
+    if (wg > 64) return 1;
+    const int ntiles = cdiv(T, KV);
+    int Z = wg <= 32 ? 8 : 4;
+    if (Z > ntiles / 2) Z = ntiles / 2;
+    return Z < 2 ? 1 : Z;
+}
+
 }  // namespace
 
 namespace ipdm {
 
-size_t attention_scratch_floats(int B, int heads, int d, int T) { return d == 64 ? attention_sx_scratch_floats(B, heads, T) : 0; }
+size_t attention_scratch_floats(int B, int heads, int d, int T)
+{
+    const size_t sx = d == 64 ? attention_sx_scratch_floats(B, heads, T) : 0;
+    const int Z = attention_kv_split(B, heads, d, T);
+    const size_t kvs = Z > 1 ? (size_t)Z * B * heads * (d + 2) * T : 0;
+    return sx > kvs ? sx : kvs;
+}
 
 int attention_launch(const float *qkv, float *out, int B, int heads, int d, int T, hipStream_t st, float *scratch)
 {
@@ -360,9 +424,11 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
         const long wg2 = (long)cdiv(T, 256) * B * heads, wg1 = (long)cdiv(T, 128) * B * heads;
         const auto eff = [](long wg) { return (double)wg / (double)(((wg + 255) / 256) * 256); };    // round quantisation
         const bool q2 = wg2 >= 256 && eff(wg2) >= eff(wg1) - 0.03;
-        dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads);
-        if (q2) hipLaunchKernelGGL((attention_ws_kernel<64, 2>), grid, dim3(512), lds, st, qkv, out, heads, T, scale);
-        else hipLaunchKernelGGL((attention_ws_kernel<64, 1>), grid, dim3(512), lds, st, qkv, out, heads, T, scale);
+        const int Z = scratch ? attention_kv_split(B, heads, d, T) : 1;
+        dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads, Z);
+        if (q2) hipLaunchKernelGGL((attention_ws_kernel<64, 2>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, 1, (float *)nullptr);
+        else hipLaunchKernelGGL((attention_ws_kernel<64, 1>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, Z, scratch);
+        if (Z > 1) hipLaunchKernelGGL((attention_combine_kernel<64>), dim3(cdiv(T, 256), B * heads), dim3(256), 0, st, scratch, out, T, Z);
     } else if (d == 64) {
         const long wg2 = (long)cdiv(T, 256) * B * heads;
         const bool q2 = wg2 >= 512 && (wg2 % 512 == 0 || wg2 >= 4 * 512);
@@ -392,7 +458,7 @@ extern "C" int ipdm_op_attention(const float *d_qkv, float *d_out, int32_t B, in
 {
     // test helper: allocates the split mode's scratch itself (the UNet executor takes it from its workspace)
     float *scratch = nullptr;
-    if (ipdm_attention_kernel_code(d) == 3) {
+    if (ipdm::attention_scratch_floats(B, heads, d, T)) {
         IPDM_HIP_CHECK(hipMalloc((void **)&scratch, ipdm::attention_scratch_floats(B, heads, d, T) * sizeof(float)));
     }
     const int rc = ipdm::attention_launch(d_qkv, d_out, B, heads, d, T, (hipStream_t)stream, scratch);

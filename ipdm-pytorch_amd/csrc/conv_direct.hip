@@ -29,15 +29,14 @@ namespace {
 constexpr int DT_W = 64, DT_H = 16;
 constexpr int DIN_P = 68;      // LDS row pitch: 16-byte aligned runs of 4 (+ halo)
 
-// 32-lane sums: DPP row rotations inside rows of 16 lanes + ds_swizzle (lane ^ 16); every lane ends with the total
+// 16-lane sums: DPP row rotations; every lane of the row ends with the total
 #define IPDM_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
-__device__ inline float sum_lanes_half(float x)
+__device__ inline float sum_lanes_row(float x)           // over the 16 lanes of the lane's DPP row
 {
     x += IPDM_DPP_F(x, 0x121);                           // row_ror:1
     x += IPDM_DPP_F(x, 0x122);                           // row_ror:2
     x += IPDM_DPP_F(x, 0x124);                           // row_ror:4
     x += IPDM_DPP_F(x, 0x128);                           // row_ror:8
-    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
     return x;
 }
 #undef IPDM_DPP_F
@@ -50,8 +49,10 @@ __device__ inline float silu_d(float v)
 
 // DKC: input channels staged per pass.  4 for CO <= 8 (20 KB of LDS and ~90 VGPRs: 5 workgroups per CU instead of 3;
 // 8->8 @2000x912 0.36 vs 0.45 ms), 8 for CO = 16 (whose 64 accumulators bound the occupancy anyway: 4 was 8 % slower).
+// (the second launch bound keeps the register budget of the main loop -- 5 workgroups per CU for CO = 8, 6 for CO = 4 --
+// when the statistics epilogue is compiled in: this loop lives on occupancy)
 template <int CO, int KS, int DKC>
-__global__ void __launch_bounds__(256) conv_direct_kernel(ConvArgs a)
+__global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_direct_kernel(ConvArgs a)
 {
     constexpr int DIN_H = DT_H + KS - 1, DIN_W = DT_W + KS - 1, DIN_CH = DIN_H * DIN_P, TAPS = KS * KS, PAD = KS / 2;
     __shared__ __attribute__((aligned(16))) float in_lds[DKC * DIN_CH];
@@ -156,8 +157,12 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(ConvArgs a)
     const size_t out_plane = (size_t)a.Ho * a.Wo;
     const bool vec = (a.Wo & 3) == 0;                      // ox is a multiple of 4: whole run inside, 16-byte aligned
     const bool full_tile = oy0 + DT_H <= a.Ho && ox0 + DT_W <= a.Wo;     // uniform: no pixel of the tile needs masking
-    __shared__ float st_lds[4][2][CO][2];                  // [wave][32-lane half][cout][sum, sum of squares]
-    const int wave = tid >> 6, lane = tid & 63;
+    // Statistics: this loop is VALU-bound, so the 256-way sums go through LDS (its pipe is idle here) instead of DPP
+    // butterflies: every thread parks its 2*CO in-lane sums in LDS ([value][thread], over the input staging area, which
+    // is dead by now), 16 threads per value then add 16 entries each and one DPP row reduction finishes the job.
+    static_assert(2 * CO * 256 <= DKC * DIN_CH, "conv_direct: statistics staging does not fit the input tile area");
+    float *st = in_lds;
+    if (a.stats) __syncthreads();                          // every thread is done reading the last chunk's tile
 #pragma unroll
     for (int co = 0; co < CO; ++co) {
         if (co < a.Cout) {
@@ -182,22 +187,24 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(ConvArgs a)
 #pragma unroll
                     for (int p = 0; p < 4; ++p) v[p] = (in_img && ox + p < a.Wo) ? v[p] : 0.0f;
                 }
-                float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-                float s2 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
-                s1 = sum_lanes_half(s1);
-                s2 = sum_lanes_half(s2);
-                if ((lane & 31) == 0) { st_lds[wave][lane >> 5][co][0] = s1; st_lds[wave][lane >> 5][co][1] = s2; }
+                st[(2 * co) * 256 + tid] = (v[0] + v[1]) + (v[2] + v[3]);
+                st[(2 * co + 1) * 256 + tid] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
             }
         }
     }
     if (a.stats) {
-        // one row of partial sums per wave: lane c adds the wave's two half sums (DS operations of a wave execute in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int row = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
-        if (lane < 2 * a.Cout) {
-            const int co = lane >> 1, k = lane & 1;
-            a.stats[(((size_t)n * a.stats_rows + row) * a.Cout + co) * 2 + k] = st_lds[wave][0][co][k] + st_lds[wave][1][co][k];
+        __syncthreads();
+        const int k = tid >> 4, j = tid & 15;              // value k (cout k/2, sum or sum of squares), 16 threads each
+        if (k < 2 * CO && (k >> 1) < a.Cout) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(st + k * 256 + j * 16);
+            const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+            float s = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) +
+                      (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
+            s = sum_lanes_row(s);
+            if (j == 0) {
+                const int row = blockIdx.y * gridDim.x + blockIdx.x;
+                a.stats[(((size_t)n * a.stats_rows + row) * a.Cout + (k >> 1)) * 2 + (k & 1)] = s;
+            }
         }
     }
 }
@@ -226,7 +233,7 @@ bool conv_direct_eligible(const ConvArgs &a)
            a.cout_pad >= 16;
 }
 
-int conv_direct_stats_rows(const ConvArgs &a) { return cdiv(a.Wo, DT_W) * cdiv(a.Ho, DT_H) * 4; }
+int conv_direct_stats_rows(const ConvArgs &a) { return cdiv(a.Wo, DT_W) * cdiv(a.Ho, DT_H); }
 
 int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
 {

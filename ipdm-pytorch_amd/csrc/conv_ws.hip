@@ -406,6 +406,26 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 voffq[q] = (t.ox0 + lx < a.Wo && oy + ly < a.Ho) ? lane_off : OOB;
                 rowq[q] = (min(oy, a.Ho - 1) * a.Wo + t.ox0) * 4;     // scalar offsets stay in range; the lanes are killed above
             }
+            // one row of per-cout partial sums {sum, sum of squares} of block row q: staged [cout][2] in LDS by the lanes
+            // that own a cout, read back as contiguous runs (DS operations of one wave execute in order, so the staging
+            // row is reused by the next q) and stored with one instruction; row index = pixel row * tile columns + column
+            auto store_stats_row = [&](int q, auto partial_tag) __attribute__((always_inline)) {
+                constexpr bool PARTIAL = decltype(partial_tag)::value;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float *sb = lds + 2 * T::BUF + swave * 256;
+                const int oy = t.oy0 + (swave * NB + q) * PBH;
+                if (oy < a.Ho && lane * 2 < T::BN) {
+                    float *dst = a.stats + (((size_t)t.n * a.stats_rows + (size_t)oy * a.tiles_x + t.ox0 / T::TW) * a.Cout + t.co0) * 2;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(sb + lane * 4);       // couts 2 lane, 2 lane + 1
+                    if (!PARTIAL) *reinterpret_cast<f32x4 *>(dst + lane * 4) = v;
+                    else {
+                        if (t.co0 + 2 * lane < a.Cout) *reinterpret_cast<f32x2 *>(dst + lane * 4) = f32x2{v[0], v[1]};
+                        if (t.co0 + 2 * lane + 1 < a.Cout) *reinterpret_cast<f32x2 *>(dst + lane * 4 + 2) = f32x2{v[2], v[3]};
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
             // PARTIAL: the tile's couts run past Cout (Cout % (32*MB) != 0): those registers are skipped by a scalar
             // branch (their scalar offset would leave the buffer); full tiles carry no such test.
             auto epilogue = [&](auto partial_tag) __attribute__((always_inline)) {
@@ -432,23 +452,21 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 }
                 if (a.stats) {
                     // fused GroupNorm statistics of the output, dword-epilogue form: the lane is a pixel, the register a
-                    // cout -> 32-lane sums per register (rare shapes: widths that are not multiples of 4)
-                    float *sb = lds + 2 * T::BUF + swave * 256;
+                    // cout -> 32-lane sums per register (rare shapes: widths that are not multiples of 4); one row of
+                    // partial sums per PIXEL ROW, like the 16-byte epilogue
 #pragma unroll
-                    for (int m = 0; m < MB; ++m)
+                    for (int q = 0; q < NB; ++q) {
+                        float *sb = lds + 2 * T::BUF + swave * 256;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float s1 = 0.0f, s2 = 0.0f;
+                        for (int m = 0; m < MB; ++m)
 #pragma unroll
-                            for (int q = 0; q < NB; ++q) {
+                            for (int r = 0; r < 16; ++r) {
                                 const float v = voffq[q] != OOB ? acc[m][q][r] : 0.0f;
-                                s1 += v;
-                                s2 = fmaf(v, v, s2);
+                                const float s1 = sum_lanes_half(v), s2 = sum_lanes_half(v * v);
+                                if (l31 == 0) *reinterpret_cast<f32x2 *>(sb + (m * 32 + 8 * (r >> 2) + (r & 3) + 4 * lk) * 2) = f32x2{s1, s2};
                             }
-                            s1 = sum_lanes_half(s1);
-                            s2 = sum_lanes_half(s2);
-                            if (l31 == 0) *reinterpret_cast<f32x2 *>(sb + (m * 32 + 8 * (r >> 2) + (r & 3) + 4 * lk) * 2) = f32x2{s1, s2};
-                        }
+                        store_stats_row(q, partial_tag);
+                    }
                 }
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
@@ -495,17 +513,15 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
 #undef IPDM_XCHG
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 // fused GroupNorm statistics of the output: after the quad transpose a lane holds 4 pixels of ONE cout
-                // (32m + 8g + (l31 & 3) + 4 lk), so the per-cout sums are formed in-lane over the 4 pixels and the NB rows
-                // and only 8 lanes (l31 >> 2) remain to be combined
-                float st1[MB][4], st2[MB][4];
+                // (32m + 8g + (l31 & 3) + 4 lk), so the per-cout sums are formed in-lane over the 4 pixels and only 8 lanes
+                // (l31 >> 2) remain to be combined.  One row of partial sums per PIXEL ROW and tile column -- the same
+                // rows in the same order whatever tile shape the launcher picked (it depends on the batch size), so the
+                // statistics, and with them every later value, do not depend on how slices are batched.
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
+                for (int q = 0; q < NB; ++q) {
+                    float st1[MB][4], st2[MB][4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) { st1[m][g] = 0.0f; st2[m][g] = 0.0f; }
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
-#pragma unroll
-                    for (int q = 0; q < NB; ++q) {
+                    for (int m = 0; m < MB; ++m) {
                         const int so = (t.co0 + m * 32) * plane4 + rowq[q];
                         f32x4 rv[4];
                         if (a.res) {
@@ -519,45 +535,27 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                             if (a.res) v += rv[g];
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4[q], so + 8 * g * plane4, 0);
                             if (a.stats) {
-                                const float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-                                const float s2 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
                                 const bool ok = voff4[q] != OOB;       // the whole run of 4 pixels is inside the image or not
-                                st1[m][g] += ok ? s1 : 0.0f;
-                                st2[m][g] += ok ? s2 : 0.0f;
+                                st1[m][g] = ok ? (v[0] + v[1]) + (v[2] + v[3]) : 0.0f;
+                                st2[m][g] = ok ? fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0]))) : 0.0f;
                             }
                         }
                     }
-                if (a.stats) {
-                    float *sb = lds + 2 * T::BUF + swave * 256;
+                    if (a.stats) {
+                        float *sb = lds + 2 * T::BUF + swave * 256;
 #pragma unroll
-                    for (int m = 0; m < MB; ++m)
+                        for (int m = 0; m < MB; ++m)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const float s1 = sum_lanes_stride4(st1[m][g]), s2 = sum_lanes_stride4(st2[m][g]);
-                            if ((l31 >> 2) == 0) *reinterpret_cast<f32x2 *>(sb + (m * 32 + 8 * g + qi + 4 * lk) * 2) = f32x2{s1, s2};
-                        }
+                            for (int g = 0; g < 4; ++g) {
+                                const float s1 = sum_lanes_stride4(st1[m][g]), s2 = sum_lanes_stride4(st2[m][g]);
+                                if ((l31 >> 2) == 0) *reinterpret_cast<f32x2 *>(sb + (m * 32 + 8 * g + qi + 4 * lk) * 2) = f32x2{s1, s2};
+                            }
+                        store_stats_row(q, std::false_type{});
+                    }
                 }
             } else {
                 if (t.co0 + T::BN <= a.Cout) epilogue(std::false_type{});
                 else epilogue(std::true_type{});
-            }
-            if (a.stats) {
-                // the wave's row of partial sums: staged [cout][2] in LDS by the lanes that own a cout, read back as
-                // contiguous runs (DS operations of one wave execute in order) and stored with one instruction
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const float *sb = lds + 2 * T::BUF + swave * 256;
-                const int row = ((t.oy0 / T::TH) * a.tiles_x + t.ox0 / T::TW) * 4 + swave;
-                float *dst = a.stats + (((size_t)t.n * a.stats_rows + row) * a.Cout + t.co0) * 2;
-                if (lane * 2 < T::BN) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(sb + lane * 4);       // couts 2 lane, 2 lane + 1
-                    if (VEC4 || t.co0 + T::BN <= a.Cout) *reinterpret_cast<f32x4 *>(dst + lane * 4) = v;
-                    else {
-                        if (t.co0 + 2 * lane < a.Cout) *reinterpret_cast<f32x2 *>(dst + lane * 4) = f32x2{v[0], v[1]};
-                        if (t.co0 + 2 * lane + 1 < a.Cout) *reinterpret_cast<f32x2 *>(dst + lane * 4 + 2) = f32x2{v[2], v[3]};
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
             }
         }
         if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_epi += now - t_last; t_last = now; }
@@ -596,8 +594,8 @@ int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
     const int cus = num_cus();
     int G = (int)(ntiles < cus ? ntiles : cus);
     G = (G + 7) / 8 * 8;
-    IPDM_REQUIRE(!a.stats || a.stats_rows == a.tiles_x * a.tiles_y * 4, "conv2d: statistics rows %d != %d", a.stats_rows,
-                 a.tiles_x * a.tiles_y * 4);
+    IPDM_REQUIRE(!a.stats || a.stats_rows == a.tiles_x * a.Ho, "conv2d: statistics rows %d != %d", a.stats_rows,
+                 a.tiles_x * a.Ho);
     if (int rc = ensure_dynamic_lds((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>, LDS_TOTAL)) return rc;
     const bool prof = prof_enabled();
     if (prof) prof_before(prof_cls, st);
@@ -645,23 +643,28 @@ static int ws_tile_couts(const ConvArgs &a)
     return 64;
 }
 
+// The number of slices depends on the layer alone (never on the batch size): a slice of a batch must stay bit-equal to
+// the same slice sampled alone or in another shard, and a different K split is a different summation order.  So only
+// layers that cannot fill the chip even at 8 slices per GPU are split: at most 16 of the 8x32-pixel x 128-cout tiles per
+// SAMPLE (256 channels at 32x32, 63x29, 32x15: 8-16 tiles).
 int conv_ws_split(const ConvArgs &a)
 {
     static const bool off = getenv("IPDM_CONV_NO_SPLITK") != nullptr;
     if (off || !a.w_interleave || a.w_interleave > 4) return 1;
-    const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, ws_tile_rows(a)) * cdiv(a.Cout, ws_tile_couts(a)) * a.B;
-    if (tiles >= 128) return 1;                     // at least half of the chip is busy already
+    const long per_sample = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128);
+    if (per_sample > 16) return 1;
     const int nch = cdiv(a.C1 + a.C2, a.ksize == 1 ? 32 : 8);
+    const int want = per_sample <= 8 ? 8 : 4;
     int best = 1;
-    for (int S = 2; S <= 8; ++S)
-        if (nch % S == 0 && nch / S >= 2 && tiles * S <= 256) best = S;
+    for (int S = 2; S <= want; ++S)
+        if (nch % S == 0 && nch / S >= 2) best = S;
     return best;
 }
 
 int conv_ws_stats_rows(const ConvArgs &a)
 {
     if (a.split_ws && conv_ws_split(a) > 1) return cdiv((long)a.Ho * a.Wo, SPLIT_PIX);
-    return cdiv(a.Ho, ws_tile_rows(a)) * cdiv(a.Wo, 32) * 4;
+    return a.Ho * cdiv(a.Wo, 32);      // one row per pixel row and 32-pixel tile column: independent of the tile variant
 }
 
 namespace {

@@ -2,18 +2,26 @@
 # Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>_*  (copy the summaries you want judged into profiles/)
 # Counters are collected in their own passes (--pmc with --kernel-trace only), never with --stats.
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-extra-legs > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
+python3 tools/rocpd_summary.py $(find $OUT/${TAG}_trace -name "*.db" | head -1) $OUT/${TAG}_bench_b8
+# whole-step HBM traffic of every kernel (per-launch averages): two separate counter passes over one bench step
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pmc_step_fetch -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-alt --no-extra-legs > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pmc_step_write -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-alt --no-extra-legs > /dev/null 2>&1
+python3 tools/traffic_summary.py $(find $OUT/${TAG}_pmc_step_fetch -name "*.db" | head -1) $(find $OUT/${TAG}_pmc_step_write -name "*.db" | head -1) ${TAG}
+cp profiles/${TAG}_traffic.json profiles/${TAG}_hbm_by_kernel.csv $OUT/
+# matrix-pipe utilisation of the two most common shapes of the dominant kernel
 for shape in "8 128 0 512 512 128 3 1 2 1" "8 64 0 512 512 64 3 1 2 1"; do
   name=$(echo $shape | tr ' ' '_')
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pmc_fetch_$name -o c -- python3 tools/one_conv.py $shape > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pmc_write_$name -o c -- python3 tools/one_conv.py $shape > /dev/null 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU --kernel-trace -d $OUT/${TAG}_pmc_sq_$name -o c -- python3 tools/one_conv.py $shape > /dev/null 2>&1
+  python3 tools/rocpd_summary.py $(find $OUT/${TAG}_pmc_sq_$name -name "*.db" | head -1) $OUT/${TAG}_pmc_sq_$name
   rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $OUT/${TAG}_pmc_grbm_$name -o c -- python3 tools/one_conv.py $shape > /dev/null 2>&1
+  python3 tools/rocpd_summary.py $(find $OUT/${TAG}_pmc_grbm_$name -name "*.db" | head -1) $OUT/${TAG}_pmc_grbm_$name
 done
-find $OUT -name "*.csv" -path "*${TAG}*" | head -40
-# whole-step HBM traffic of every kernel (per-launch averages): two separate counter passes over one bench step
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pmc_step_fetch -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pmc_step_write -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+ls $OUT | grep ${TAG}_ | head -40
+# the databases are large (the merge back is capped at 64 MiB): keep the summaries only
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_step_fetch $OUT/${TAG}_pmc_step_write $OUT/${TAG}_pmc_sq_* $OUT/${TAG}_pmc_grbm_*/ 2>/dev/null
+find $OUT -maxdepth 1 -type d -name "${TAG}_pmc_*" -exec rm -rf {} + 2>/dev/null
+ls -la $OUT | grep ${TAG}_ | head -40
