@@ -423,8 +423,8 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
         if (int rc = ensure_dynamic_lds((const void *)attention_ws_kernel<64, 2>, lds)) return rc;
         const long wg2 = (long)cdiv(T, 256) * B * heads, wg1 = (long)cdiv(T, 128) * B * heads;
         const auto eff = [](long wg) { return (double)wg / (double)(((wg + 255) / 256) * 256); };    // round quantisation
-        const bool q2 = wg2 >= 256 && eff(wg2) >= eff(wg1) - 0.03;
         const int Z = scratch ? attention_kv_split(B, heads, d, T) : 1;
+        const bool q2 = Z == 1 && wg2 >= 256 && eff(wg2) >= eff(wg1) - 0.03;     // (the key-slice form exists for 32-query waves)
         dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads, Z);
         if (q2) hipLaunchKernelGGL((attention_ws_kernel<64, 2>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, 1, (float *)nullptr);
         else hipLaunchKernelGGL((attention_ws_kernel<64, 1>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, Z, scratch);

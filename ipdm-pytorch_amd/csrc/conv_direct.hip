@@ -194,16 +194,19 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
     }
     if (a.stats) {
         __syncthreads();
-        const int k = tid >> 4, j = tid & 15;              // value k (cout k/2, sum or sum of squares), 16 threads each
-        if (k < 2 * CO && (k >> 1) < a.Cout) {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(st + k * 256 + j * 16);
-            const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
-            float s = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) +
-                      (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
-            s = sum_lanes_row(s);
-            if (j == 0) {
-                const int row = blockIdx.y * gridDim.x + blockIdx.x;
-                a.stats[(((size_t)n * a.stats_rows + row) * a.Cout + (k >> 1)) * 2 + (k & 1)] = s;
+        const int j = tid & 15;                            // 16 threads per value (cout k/2, sum or sum of squares)
+#pragma unroll
+        for (int k = tid >> 4; k < 2 * CO; k += 16) {
+            if ((k >> 1) < a.Cout) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(st + k * 256 + j * 16);
+                const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+                float s = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) +
+                          (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
+                s = sum_lanes_row(s);
+                if (j == 0) {
+                    const int row = blockIdx.y * gridDim.x + blockIdx.x;
+                    a.stats[(((size_t)n * a.stats_rows + row) * a.Cout + (k >> 1)) * 2 + (k & 1)] = s;
+                }
             }
         }
     }

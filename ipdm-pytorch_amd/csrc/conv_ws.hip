@@ -47,8 +47,9 @@ namespace {
 
 // IL: cout interleave of the packed weights (>= MB).  PBW: the 32 pixels of one MFMA operand are PBW columns x 32/PBW rows
 // (32x1 by default; 8x4 for image widths with a large remainder modulo 32: 228, 114)
-template <int KS, int STRIDE, int MB, int NB, int KC_, int IL = MB, int PBW = 32>
+template <int KS, int STRIDE, int MB, int NB, int KC_, int IL = MB, int PBW_ = 32>
 struct WsTile {
+    static constexpr int PBW = PBW_;
     static constexpr int KC = KC_;
     static constexpr int TAPS = KS * KS;
     static constexpr int PBH = 32 / PBW;
@@ -70,6 +71,16 @@ struct WsTile {
     static constexpr int BUF = IN_TILE + W_TILEP;
     static constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(float);
 };
+
+// extra LDS behind the two stages: 4 x 256 floats of statistics rows, and (when it fits) 4 x 32 x 36 floats through which
+// the 16-byte epilogue transposes its accumulators
+#ifndef IPDM_EPI_DPP
+#define IPDM_EPI_DPP 0
+#endif
+template <class T, bool VEC4>
+constexpr bool ws_lds_transpose() { return !IPDM_EPI_DPP && VEC4 && T::PBW == 32 && T::LDS_BYTES + 4 * 256 * 4 + 4 * 32 * 36 * 4 <= 160 * 1024; }
+template <class T, bool VEC4>
+constexpr size_t ws_lds_total() { return T::LDS_BYTES + 4 * 256 * 4 + (ws_lds_transpose<T, VEC4>() ? 4 * 32 * 36 * 4 : 0); }
 
 struct TileId { int n, oy0, ox0, co0, ks; };      // ks: which slice of the K (input channel) range, ConvArgs::ksplit
 
@@ -137,6 +148,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
 {
     using T = WsTile<KS, STRIDE, MB, NB, KC, IL, PBW>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool LDSTR = ws_lds_transpose<T, VEC4>();
 
     // ---- static tile schedule: at step k the G workgroups cover tiles [kG,(k+1)G); the workgroups of one XCD
     //      (blockIdx % 8) take a contiguous run of them, so the cout tiles / halo neighbours that re-read the
@@ -497,7 +509,22 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 for (int q = 0; q < NB; ++q) voff4[q] = (xok && t.oy0 + (swave * NB + q) * PBH + ly < a.Ho) ? lane_off4 : OOB;
                 const bool odd = (l31 & 1) != 0, hi = (l31 & 2) != 0;
 #define IPDM_XCHG(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
+                // LDSTR: the same 4x4 transposes through LDS instead (the LDS pipe idles during the epilogue, the vector
+                // ALU is what the MFMAs of the next tile want): a wave parks one 32-cout x 32-pixel accumulator
+                // [cout][36] and reads 16-byte runs back; DS operations of a wave execute in order, so no barrier.
+                constexpr int TRP = 36;
+                float *tb = lds + 2 * T::BUF + 4 * 256 + swave * (32 * TRP);
+                auto park = [&](int m, int q) __attribute__((always_inline)) {
+                    if constexpr (LDSTR) {
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) tb[(8 * (r >> 2) + (r & 3) + 4 * lk) * TRP + l31] = acc[m][q][r];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                };
                 auto block = [&](int m, int q, int g) __attribute__((always_inline)) -> f32x4 {
+                    if constexpr (LDSTR) return *reinterpret_cast<const f32x4 *>(tb + (8 * g + qi + 4 * lk) * TRP + 4 * qx);
                     float r0 = acc[m][q][4 * g], r1 = acc[m][q][4 * g + 1], r2 = acc[m][q][4 * g + 2], r3 = acc[m][q][4 * g + 3];
                     // lanes i^1 exchange registers j^1 (quad_perm [1,0,3,2]), then lanes i^2 exchange registers j^2 ([2,3,0,1])
                     float x = IPDM_XCHG(r0, 0xB1), y = IPDM_XCHG(r1, 0xB1);
@@ -517,22 +544,30 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 // (l31 >> 2) remain to be combined.  One row of partial sums per PIXEL ROW and tile column -- the same
                 // rows in the same order whatever tile shape the launcher picked (it depends on the batch size), so the
                 // statistics, and with them every later value, do not depend on how slices are batched.
+                // residual: 16-byte loads, one (row block, cout block) AHEAD of its use.  VMEM operations retire through one
+                // in-order counter: a load issued behind the previous block's stores would wait for those stores to reach
+                // memory, and its own latency would be exposed once per block (8 times per tile).
+                f32x4 rv[2][4];
+                auto load_res = [&](int q, int m, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+                    const int so = (t.co0 + m * 32) * plane4 + rowq[q];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        dst[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4[q], so + 8 * g * plane4, 0));
+                };
+                if (a.res) load_res(0, 0, rv[0]);
 #pragma unroll
                 for (int q = 0; q < NB; ++q) {
                     float st1[MB][4], st2[MB][4];
 #pragma unroll
                     for (int m = 0; m < MB; ++m) {
+                        const int i = q * MB + m;
                         const int so = (t.co0 + m * 32) * plane4 + rowq[q];
-                        f32x4 rv[4];
-                        if (a.res) {
-#pragma unroll
-                            for (int g = 0; g < 4; ++g)
-                                rv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4[q], so + 8 * g * plane4, 0));
-                        }
+                        if (a.res && i + 1 < NB * MB) load_res((i + 1) / MB, (i + 1) % MB, rv[(i + 1) & 1]);
+                        park(m, q);
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             f32x4 v = block(m, q, g);
-                            if (a.res) v += rv[g];
+                            if (a.res) v += rv[i & 1][g];
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4[q], so + 8 * g * plane4, 0);
                             if (a.stats) {
                                 const bool ok = voff4[q] != OOB;       // the whole run of 4 pixels is inside the image or not
@@ -572,7 +607,7 @@ template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4
 int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
 {
     using T = WsTile<KS, STRIDE, MB, NB, KC, IL, PBW>;
-    constexpr size_t LDS_TOTAL = T::LDS_BYTES + 4 * 256 * sizeof(float);      // + the statistics rows of the 4 consumer waves
+    constexpr size_t LDS_TOTAL = ws_lds_total<T, VEC4>();      // stages + statistics rows (+ transpose staging)
     static_assert(LDS_TOTAL <= 160 * 1024, "conv_ws: LDS stages exceed 160 KiB");
     ConvArgs a = args;
     // IPDM_CONV_DBG=8: in-kernel s_memtime stamps per phase (tools/bench_conv_dbg.py; needs a.dbg_buf, bench entry only)

@@ -1,0 +1,27 @@
+"""A/B of two builds of libipdm_hip.so in ONE process, interleaved rounds (rule: perf deltas from interleaved rounds):
+   python tools/ab_lib.py ipdm-pytorch_amd/libipdm_hip.so ipdm-pytorch_amd/libipdm_hip_dpp.so"""
+import ctypes as C
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+torch.zeros(1, device="cuda")
+libs = [C.CDLL(os.path.abspath(p)) for p in sys.argv[1:3]]
+for l in libs:
+    l.ipdm_bench_conv2d.argtypes = [C.c_int32] * 11 + [C.POINTER(C.c_float)]
+CONVS = [  # B, C1, C2, H, W, Cout, ks, stride, act, res
+    (8, 64, 0, 512, 512, 64, 3, 1, 2, 1), (8, 128, 0, 256, 256, 128, 3, 1, 2, 1), (8, 64, 64, 512, 512, 64, 3, 1, 2, 0),
+    (8, 128, 0, 228, 500, 128, 3, 1, 2, 1), (8, 128, 0, 512, 512, 128, 3, 1, 0, 0), (8, 256, 0, 64, 64, 256, 3, 1, 2, 1),
+    (8, 256, 0, 64, 64, 768, 1, 1, 1, 0), (8, 128, 128, 228, 500, 128, 1, 1, 0, 0), (8, 128, 128, 228, 500, 128, 3, 1, 2, 0),
+]
+ms = C.c_float()
+res = {}
+for rnd in range(4):
+    for c in CONVS:
+        for i, l in enumerate(libs):
+            assert l.ipdm_bench_conv2d(*c, 10, C.byref(ms)) == 0
+            res.setdefault((c, i), []).append(ms.value)
+for c in CONVS:
+    B, C1, C2, H, W, Co, ks, st, act, r = c
+    fl = 2.0 * B * H * W * Co * (C1 + C2) * ks * ks
+    a, b = min(res[(c, 0)]), min(res[(c, 1)])
+    print("conv %-42s A %.3f ms %6.1f TF/s | B %.3f ms %6.1f TF/s | A/B %+.1f%%" % (c, a, fl / a / 1e9, b, fl / b / 1e9, 100 * (a / b - 1)))
