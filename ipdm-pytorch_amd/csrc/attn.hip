@@ -351,25 +351,34 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
     }
 }
 
-// merges the key slices of a split launch: out = sum_z w_z o_z / sum_z w_z l_z, w_z = exp(m_z - max m)
+// merges the key slices of a split launch: out = sum_z w_z o_z / sum_z w_z l_z, w_z = exp(m_z - max m).
+// Block = (256 queries, sample*head, 16 of the D channels): the weights are recomputed per channel group (2 Z loads) so that
+// four times as many blocks stream the partial outputs.
 template <int D>
 __global__ void __launch_bounds__(256) attention_combine_kernel(const float *__restrict__ part, float *__restrict__ out, int T, int Z)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x, bh = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x, bh = blockIdx.y, c0 = blockIdx.z * 16;
     if (t >= T) return;
     const size_t slice = (size_t)gridDim.y * (D + 2) * T;
     const float *p = part + (size_t)bh * (D + 2) * T;
     float m = -INFINITY;
     for (int z = 0; z < Z; ++z) m = fmaxf(m, p[z * slice + (size_t)D * T + t]);
     float w[8], L = 0.0f;
-    for (int z = 0; z < Z; ++z) {
-        w[z] = __builtin_amdgcn_exp2f((p[z * slice + (size_t)D * T + t] - m) * LOG2E);      // an empty slice has m = -inf: weight 0
-        L = fmaf(w[z], p[z * slice + (size_t)(D + 1) * T + t], L);
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {
+        w[z] = 0.0f;
+        if (z < Z) {
+            w[z] = __builtin_amdgcn_exp2f((p[z * slice + (size_t)D * T + t] - m) * LOG2E);   // an empty slice has m = -inf: weight 0
+            L = fmaf(w[z], p[z * slice + (size_t)(D + 1) * T + t], L);
+        }
     }
     const float inv = 1.0f / L;
-    for (int c = 0; c < D; ++c) {
+#pragma unroll 4
+    for (int c = c0; c < c0 + 16; ++c) {
         float acc = 0.0f;
-        for (int z = 0; z < Z; ++z) acc = fmaf(w[z], p[z * slice + (size_t)c * T + t], acc);
+#pragma unroll
+        for (int z = 0; z < 8; ++z)
+            if (z < Z) acc = fmaf(w[z], p[z * slice + (size_t)c * T + t], acc);
         out[((size_t)bh * D + c) * T + t] = acc * inv;
     }
 }
@@ -428,7 +437,7 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
         dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads, Z);
         if (q2) hipLaunchKernelGGL((attention_ws_kernel<64, 2>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, 1, (float *)nullptr);
         else hipLaunchKernelGGL((attention_ws_kernel<64, 1>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, Z, scratch);
-        if (Z > 1) hipLaunchKernelGGL((attention_combine_kernel<64>), dim3(cdiv(T, 256), B * heads), dim3(256), 0, st, scratch, out, T, Z);
+        if (Z > 1) hipLaunchKernelGGL((attention_combine_kernel<64>), dim3(cdiv(T, 256), B * heads, 4), dim3(256), 0, st, scratch, out, T, Z);
     } else if (d == 64) {
         const long wg2 = (long)cdiv(T, 256) * B * heads;
         const bool q2 = wg2 >= 512 && (wg2 % 512 == 0 || wg2 >= 4 * 512);

@@ -72,15 +72,9 @@ struct WsTile {
     static constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(float);
 };
 
-// extra LDS behind the two stages: 4 x 256 floats of statistics rows, and (when it fits) 4 x 32 x 36 floats through which
-// the 16-byte epilogue transposes its accumulators
-#ifndef IPDM_EPI_DPP
-#define IPDM_EPI_DPP 0
-#endif
-template <class T, bool VEC4>
-constexpr bool ws_lds_transpose() { return !IPDM_EPI_DPP && VEC4 && T::PBW == 32 && T::LDS_BYTES + 4 * 256 * 4 + 4 * 32 * 36 * 4 <= 160 * 1024; }
-template <class T, bool VEC4>
-constexpr size_t ws_lds_total() { return T::LDS_BYTES + 4 * 256 * 4 + (ws_lds_transpose<T, VEC4>() ? 4 * 32 * 36 * 4 : 0); }
+// extra LDS behind the two stages: 4 x 256 floats, the statistics rows of the 4 consumer waves
+template <class T>
+constexpr size_t ws_lds_total() { return T::LDS_BYTES + 4 * 256 * 4; }
 
 struct TileId { int n, oy0, ox0, co0, ks; };      // ks: which slice of the K (input channel) range, ConvArgs::ksplit
 
@@ -148,7 +142,6 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
 {
     using T = WsTile<KS, STRIDE, MB, NB, KC, IL, PBW>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr bool LDSTR = ws_lds_transpose<T, VEC4>();
 
     // ---- static tile schedule: at step k the G workgroups cover tiles [kG,(k+1)G); the workgroups of one XCD
     //      (blockIdx % 8) take a contiguous run of them, so the cout tiles / halo neighbours that re-read the
@@ -499,32 +492,27 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
             // every quad of lanes (DPP quad_perm + select, 8-16 VALU per block) turns that into 4 consecutive PIXELS of one
             // cout per lane, so one buffer_store_dwordx4 replaces four dword stores (the store path retires ~1 instruction
             // per 100 cycles per wave regardless of its width) and a half-wave still writes 4 full 128-byte row segments.
-            if constexpr (VEC4) {       // launcher: Wo % 4 == 0 and Cout % (32*MB) == 0
+            if constexpr (VEC4) {       // launcher: Cout % (32*MB) == 0
                 const int qi = l31 & 3;
                 const int qx = lx >> 2;                                    // quad of 4 consecutive columns inside the block row
                 const int lane_off4 = ((qi + 4 * lk) * out_plane + ly * a.Wo + 4 * qx) * 4;
                 const bool xok = t.ox0 + 4 * qx + 4 <= a.Wo;
+                // widths that are not multiples of 4 (250, 125, 63 ... of the projection domain): the run of 4 pixels that
+                // straddles the right edge of the image is stored element by element by its lane (ragged: the tile touches
+                // the edge, wave-uniform); every other run takes the 16-byte path, at dword alignment
+                const bool ragged = t.ox0 + 32 > a.Wo && (a.Wo & 3) != 0;
+                const int nval = a.Wo - (t.ox0 + 4 * qx);                   // valid pixels of the lane's run (1..3 when partial)
                 int voff4[NB];
+                bool part[NB];
 #pragma unroll
-                for (int q = 0; q < NB; ++q) voff4[q] = (xok && t.oy0 + (swave * NB + q) * PBH + ly < a.Ho) ? lane_off4 : OOB;
+                for (int q = 0; q < NB; ++q) {
+                    const bool rok = t.oy0 + (swave * NB + q) * PBH + ly < a.Ho;
+                    voff4[q] = (xok && rok) ? lane_off4 : OOB;
+                    part[q] = ragged && !xok && nval > 0 && rok;
+                }
                 const bool odd = (l31 & 1) != 0, hi = (l31 & 2) != 0;
 #define IPDM_XCHG(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
-                // LDSTR: the same 4x4 transposes through LDS instead (the LDS pipe idles during the epilogue, the vector
-                // ALU is what the MFMAs of the next tile want): a wave parks one 32-cout x 32-pixel accumulator
-                // [cout][36] and reads 16-byte runs back; DS operations of a wave execute in order, so no barrier.
-                constexpr int TRP = 36;
-                float *tb = lds + 2 * T::BUF + 4 * 256 + swave * (32 * TRP);
-                auto park = [&](int m, int q) __attribute__((always_inline)) {
-                    if constexpr (LDSTR) {
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) tb[(8 * (r >> 2) + (r & 3) + 4 * lk) * TRP + l31] = acc[m][q][r];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                };
                 auto block = [&](int m, int q, int g) __attribute__((always_inline)) -> f32x4 {
-                    if constexpr (LDSTR) return *reinterpret_cast<const f32x4 *>(tb + (8 * g + qi + 4 * lk) * TRP + 4 * qx);
                     float r0 = acc[m][q][4 * g], r1 = acc[m][q][4 * g + 1], r2 = acc[m][q][4 * g + 2], r3 = acc[m][q][4 * g + 3];
                     // lanes i^1 exchange registers j^1 (quad_perm [1,0,3,2]), then lanes i^2 exchange registers j^2 ([2,3,0,1])
                     float x = IPDM_XCHG(r0, 0xB1), y = IPDM_XCHG(r1, 0xB1);
@@ -563,14 +551,23 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                         const int i = q * MB + m;
                         const int so = (t.co0 + m * 32) * plane4 + rowq[q];
                         if (a.res && i + 1 < NB * MB) load_res((i + 1) / MB, (i + 1) % MB, rv[(i + 1) & 1]);
-                        park(m, q);
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             f32x4 v = block(m, q, g);
                             if (a.res) v += rv[i & 1][g];
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4[q], so + 8 * g * plane4, 0);
+                            if (ragged) {            // wave-uniform; the partial run's residual was not loaded above (its offset is OOB)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int vo = (part[q] && j < nval) ? lane_off4 + 4 * j : OOB;
+                                    float e = v[j];
+                                    if (a.res) e += bload(r_rsrc, vo, so + 8 * g * plane4);
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e), o_rsrc, vo, so + 8 * g * plane4, 0);
+                                    if (part[q]) v[j] = j < nval ? e : 0.0f;
+                                }
+                            }
                             if (a.stats) {
-                                const bool ok = voff4[q] != OOB;       // the whole run of 4 pixels is inside the image or not
+                                const bool ok = voff4[q] != OOB || (ragged && part[q]);      // (a partial run has its tail zeroed above)
                                 st1[m][g] = ok ? (v[0] + v[1]) + (v[2] + v[3]) : 0.0f;
                                 st2[m][g] = ok ? fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0]))) : 0.0f;
                             }
@@ -607,7 +604,7 @@ template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4
 int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
 {
     using T = WsTile<KS, STRIDE, MB, NB, KC, IL, PBW>;
-    constexpr size_t LDS_TOTAL = ws_lds_total<T, VEC4>();      // stages + statistics rows (+ transpose staging)
+    constexpr size_t LDS_TOTAL = ws_lds_total<T>();      // stages + statistics rows
     static_assert(LDS_TOTAL <= 160 * 1024, "conv_ws: LDS stages exceed 160 KiB");
     ConvArgs a = args;
     // IPDM_CONV_DBG=8: in-kernel s_memtime stamps per phase (tools/bench_conv_dbg.py; needs a.dbg_buf, bench entry only)
@@ -640,13 +637,14 @@ int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
     return IPDM_OK;
 }
 
-// the 16-byte-store epilogue needs whole runs of 4 pixels per row and whole cout tiles; everything else takes the
+// the 16-byte-store epilogue needs whole cout tiles (a ragged right edge is handled inside it); everything else takes the
 // dword epilogue (with its ragged-cout variant).  Two kernels instead of one keep either epilogue out of the other's
 // register allocation.
 template <int KS, int STRIDE, int MB, int NB, int KC, int IL = MB, int PBW = 32>
 int launch_ws(const ConvArgs &a, hipStream_t st, int prof_cls)
 {
-    if ((a.Wo & 3) == 0 && a.Cout % (32 * MB) == 0) return launch_ws_v<KS, STRIDE, MB, NB, KC, IL, PBW, true>(a, st, prof_cls);
+    static const bool strict = getenv("IPDM_CONV_VEC4_STRICT") != nullptr;     // A/B: rows of whole 4-pixel runs only, as in round 1
+    if ((!strict || (a.Wo & 3) == 0) && a.Cout % (32 * MB) == 0) return launch_ws_v<KS, STRIDE, MB, NB, KC, IL, PBW, true>(a, st, prof_cls);
     return launch_ws_v<KS, STRIDE, MB, NB, KC, IL, PBW, false>(a, st, prof_cls);
 }
 

@@ -308,6 +308,11 @@ def _conv_case(B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res, seed):
     (1, 256, 0, 16, 16, 16, 16, 768, 1, 1, 1, False),       # 1x1 (qkv) with GN, K split into 4
     (1, 256, 0, 31, 45, 31, 45, 256, 3, 2, 0, False),       # stride 2, K split
     (1, 192, 0, 29, 63, 29, 63, 72, 3, 1, 2, True),         # K split with ragged couts and width % 4 != 0
+    (2, 128, 0, 19, 250, 19, 250, 128, 3, 1, 2, True),      # width % 4 == 2: 16-byte epilogue with a ragged last run (2 pixels)
+    (2, 256, 0, 13, 125, 13, 125, 256, 3, 1, 2, True),      # width % 4 == 1, residual on the partial run
+    (2, 128, 0, 21, 63, 21, 63, 128, 3, 1, 0, False),       # width % 4 == 3, 63 columns = one full + one ragged tile column
+    (2, 256, 0, 17, 57, 17, 57, 256, 1, 1, 0, True),        # 1x1 with residual, width % 4 == 1
+    (2, 64, 0, 37, 117, 19, 59, 128, 3, 2, 0, False),       # stride 2 to 19x59
 ])
 def test_conv_kernel(case):
     _conv_case(*case, seed=200 + sum(case[:8]))
@@ -465,6 +470,8 @@ def test_reference_blocks_golden(golden):
     (8, 256, 32, 32, 256, 3, 1, True, 2, 64),     # the small-tile variant (4x32x64)
     (1, 256, 32, 32, 256, 3, 1, True, 2, 64),     # batch 1: K split, statistics from the combine pass
     (1, 256, 24, 40, 256, 1, 1, True, 2, 64),     # 1x1 producer, K split
+    (2, 128, 26, 250, 128, 3, 1, True, 2, 64),    # width % 4 == 2 through the 16-byte epilogue: partial runs in the statistics
+    (2, 128, 40, 125, 256, 3, 1, False, 2, 64),   # width % 4 == 1
     (2, 8, 70, 200, 8, 3, 1, True, 2, 8),         # direct narrow kernel 8 -> 8, ragged tiles
     (1, 16, 37, 130, 16, 3, 1, False, 2, 16),     # direct kernel 16 couts, width % 4 != 0
     (1, 1, 64, 72, 4, 3, 1, False, 2, 8),         # stem 1 -> 4
