@@ -385,16 +385,17 @@ __global__ void __launch_bounds__(256) attention_combine_kernel(const float *__r
 
 // Key slices of the wave-specialised kernel.  Like the K split of the convolutions the count depends on the layer alone
 // (T and the head count, never the batch size), so that a slice of a batch stays bit-equal to the slice sampled alone:
-// only sequences that cannot fill the chip even at 8 slices per GPU are split (at most 64 query workgroups per sample).
+// only short sequences are split (at most 128 query workgroups per sample: T <= 4096 with 4 heads -- one slice alone fills
+// half of the chip; at 8 slices per GPU the split costs those launches a few per cent for the combine pass).
 int attention_kv_split(int B, int heads, int d, int T)
 {
     static const bool off = getenv("IPDM_ATTN_NO_KVSPLIT") != nullptr;
     (void)B;
     if (off || d != 64) return 1;
     const long wg = (long)cdiv(T, 128) * heads;
-    if (wg > 64) return 1;
+    if (wg > 128) return 1;
     const int ntiles = cdiv(T, KV);
-    int Z = wg <= 32 ? 8 : 4;
+    int Z = wg <= 32 ? 8 : (wg <= 64 ? 4 : 2);
     if (Z > ntiles / 2) Z = ntiles / 2;
     return Z < 2 ? 1 : Z;
 }
