@@ -1,5 +1,5 @@
 """HBM traffic of the dominant kernel from the two whole-step counter passes of tools/profile_round.sh
-(rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over `bench.py --steps 1 --warmup 0`, separate runs):
+(rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over a reduced `bench.py` step with the headline's mix of forwards, separate runs):
 
     python tools/traffic_summary.py <fetch results.db> <write results.db> <tag>   ->  profiles/<tag>_traffic.json
                                                                                        profiles/<tag>_hbm_by_kernel.csv
@@ -42,7 +42,8 @@ def main(fetch_db, write_db, tag):
         sha = hashlib.sha256(fh.read()).hexdigest()[:16]
     mode = {"3": "split-bf16-x6", "2": "split-bf16-x3"}.get(os.environ.get("IPDM_CONV_SPLIT", ""), "exact-f32")
     d = {"tag": tag, "kernel": "conv_ws_kernel<3,1,*> (3x3 stride-1)", "mode": mode, "kernel_source_sha16": sha,
-         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python3 bench.py --steps 1 --warmup 0 (B=8)",
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python3 bench.py --steps 1 --warmup 0 "
+                   "--t_start_proj 3 --t_start_img 2 --no-ultra (B=8: the headline's 3:2 mix of proj and img UNet forwards)",
          "launches": nl, "fetch_size_bytes_per_launch_raw": fetch, "fetch_calibration_factor": 2.0,
          "fetch_bytes_per_launch": 2.0 * fetch, "write_bytes_per_launch": write,
          "traffic_bytes_per_launch": 2.0 * fetch + write}
