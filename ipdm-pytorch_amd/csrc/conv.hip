@@ -52,6 +52,19 @@ struct ConvTile {
     static constexpr size_t LDS_BYTES = (size_t)2 * (IN_TILE + W_TILE) * sizeof(float);
 };
 
+// 32-lane sums (DPP row rotations + ds_swizzle across the two rows of a half): fused GroupNorm statistics of the output
+#define IPDM_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
+__device__ inline float igemm_sum_half(float x)
+{
+    x += IPDM_DPP_F(x, 0x121);
+    x += IPDM_DPP_F(x, 0x122);
+    x += IPDM_DPP_F(x, 0x124);
+    x += IPDM_DPP_F(x, 0x128);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
+    return x;
+}
+#undef IPDM_DPP_F
+
 // SiLU with the hardware exp2/rcp (each ~1 ulp): |err| ~ 3e-7 relative, far inside the parity budget
 __device__ inline float silu_fast(float v)
 {
@@ -266,6 +279,19 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a)
     const int ox = ox0 + l31;
     const size_t out_plane = (size_t)a.Ho * a.Wo;
     const bool full = (oy0 + T::TH <= a.Ho) && (ox0 + T::TW <= a.Wo) && (co0 + T::BN <= a.Cout);   // workgroup-uniform
+    // fused GroupNorm statistics of the output (ConvArgs::stats): one row of per-cout partial sums per pixel row and
+    // tile column, as conv_ws writes them; this kernel only serves a few narrow layers, so the plain form: a 32-lane sum
+    // per accumulator register, one lane of each half stores its cout's pair
+    const int tile_col = ox0 / T::TW;
+    auto stat_row = [&](float v, bool ok, int oy, int co) __attribute__((always_inline)) {
+        const float x = ok ? v : 0.0f;
+        const float s1 = igemm_sum_half(x), s2 = igemm_sum_half(x * x);
+        if (l31 == 0 && oy < a.Ho && co < a.Cout) {
+            float *d = a.stats + (((size_t)n * a.stats_rows + (size_t)oy * a.tiles_x + tile_col) * a.Cout + co) * 2;
+            d[0] = s1;
+            d[1] = s2;
+        }
+    };
     if (full) {
         // fast path: no bounds checks, all residual loads of a 32x32 tile in flight together
 #pragma unroll
@@ -287,6 +313,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a)
                     float v = acc[m][q][r] + bv[r];
                     if (a.res) v += rv[r];
                     a.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * out_plane] = v;
+                    if (a.stats) stat_row(v, true, oy, co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk);
                 }
             }
         }
@@ -299,13 +326,16 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (co < a.Cout && oy < a.Ho && ox < a.Wo) {
+                    const bool ok = co < a.Cout && oy < a.Ho && ox < a.Wo;
+                    float v = 0.0f;
+                    if (ok) {
                         const size_t o = ((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wo + ox;
-                        float v = acc[m][q][r];
+                        v = acc[m][q][r];
                         if (a.bias) v += a.bias[co];
                         if (a.res) v += a.res[o];
                         a.out[o] = v;
                     }
+                    if (a.stats) stat_row(v, ok, oy, co);
                 }
             }
     }
@@ -361,7 +391,7 @@ int conv_stats_rows(const ConvArgs &a)
     if (a.w_interleave) return conv_ws_stats_rows(a);
     static const bool no_direct = getenv("IPDM_CONV_NO_DIRECT") != nullptr;
     if (!no_direct && conv_direct_eligible(a)) return conv_direct_stats_rows(a);
-    return 0;                                                           // legacy 4-wave kernels
+    return a.Ho * cdiv(a.Wo, 32);                                       // the 4-wave kernels below: a row per pixel row and tile column
 }
 
 int conv_split(const ConvArgs &a)

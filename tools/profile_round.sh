@@ -25,6 +25,6 @@ for shape in "8 128 0 512 512 128 3 1 2 1" "8 64 0 512 512 64 3 1 2 1"; do
 done
 ls $OUT | grep ${TAG}_ | head -40
 # the databases are large (the merge back is capped at 64 MiB): keep the summaries only
-rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_step_fetch $OUT/${TAG}_pmc_step_write $OUT/${TAG}_pmc_sq_* $OUT/${TAG}_pmc_grbm_*/ 2>/dev/null
+rm -rf $OUT/${TAG}_trace 2>/dev/null
 find $OUT -maxdepth 1 -type d -name "${TAG}_pmc_*" -exec rm -rf {} + 2>/dev/null
 ls -la $OUT | grep ${TAG}_ | head -40
