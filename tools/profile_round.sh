@@ -10,11 +10,13 @@ python3 tools/rocpd_summary.py $(find $OUT/${TAG}_trace -name "*.db" | head -1) 
 # HBM traffic of every kernel (per-launch averages): two separate counter passes.  A counter pass serialises every
 # dispatch (a full step of 23k launches takes > 25 minutes), so the passes run a step with the same 3 : 2 mix of proj and
 # img UNet forwards as the headline (45 : 30) but one fifteenth of them: t_start_proj=[3], t_start_img=[2], no ultra
+if [ -z "$SKIP_TRAFFIC" ]; then
 RED="--steps 1 --warmup 0 --t_start_proj 3 --t_start_img 2 --no-ultra --no-cpu-baseline --no-roofline --no-alt --no-extra-legs"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_pmc_step_fetch -o s -- python3 bench.py $RED > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pmc_step_write -o s -- python3 bench.py $RED > /dev/null 2>&1
 python3 tools/traffic_summary.py $(find $OUT/${TAG}_pmc_step_fetch -name "*.db" | head -1) $(find $OUT/${TAG}_pmc_step_write -name "*.db" | head -1) ${TAG}
 cp profiles/${TAG}_traffic.json profiles/${TAG}_hbm_by_kernel.csv $OUT/
+fi
 # matrix-pipe utilisation of the two most common shapes of the dominant kernel
 for shape in "8 128 0 512 512 128 3 1 2 1" "8 64 0 512 512 64 3 1 2 1"; do
   name=$(echo $shape | tr ' ' '_')
