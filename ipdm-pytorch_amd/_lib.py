@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libipdm_hip.so")
+LIB_PATH = os.environ.get("IPDM_LIB_PATH") or os.path.join(_HERE, "libipdm_hip.so")    # (override: diagnostic builds)
 
 
 class IpdmError(RuntimeError):

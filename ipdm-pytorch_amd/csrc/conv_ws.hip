@@ -76,6 +76,13 @@ struct WsTile {
 template <class T>
 constexpr size_t ws_lds_total() { return T::LDS_BYTES + 4 * 256 * 4; }
 
+// In-kernel s_memtime stamps of the consumer / producer phases (tools/bench_conv_dbg.py) are compiled in only with
+// -DIPDM_CONV_STAMPS=1 (`make stamps` builds ../libipdm_hip_stamps.so): their ten 64-bit counters cost scalar registers the
+// persistent loops need -- spilled SGPRs come back as v_readlane, and a producer's VALU instructions only get the stall
+// gaps of the MFMA wave.  Compiled out: 3x3 convolutions 1.2 % faster, 1x1 6 % (tools/ab_lib.py, interleaved).
+#ifndef IPDM_CONV_STAMPS
+#define IPDM_CONV_STAMPS 0
+#endif
 struct TileId { int n, oy0, ox0, co0, ks; };      // ks: which slice of the K (input channel) range, ConvArgs::ksplit
 
 template <int TH, int TW, int BN>
@@ -179,7 +186,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
         bool in_ok[T::SP];
         TileId t = {0, 0, 0, 0};
         bool border = false;
-        const bool pstamp = (a.dbg & 8) != 0;
+        const bool pstamp = IPDM_CONV_STAMPS && (a.dbg & 8) != 0;
         unsigned long long p_issue = 0, p_wait = 0, p_math = 0, p_store = 0, p_t = 0;
         for (int s = 0; s < S; ++s) {
             if (pstamp) p_t = __builtin_amdgcn_s_memtime();
@@ -243,8 +250,8 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                     float scv[KC], shv[KC];
 #pragma unroll
                     for (int c = 0; c < KC; ++c) {
-                        scv[c] = c < nvalid ? gsc[c] : 0.0f;
-                        shv[c] = c < nvalid ? gsh[c] : 0.0f;
+                        scv[c] = gsc[c];           // (no `c < nvalid` selects: channels beyond Cin have zero weights, and the
+                        shv[c] = gsh[c];           //  arrays are padded by a K chunk -- 16 starved VALU instructions fewer)
                     }
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_wait += now - p_t; p_t = now; }
@@ -303,7 +310,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     f32x16 acc[MB][NB];
     int sub = 0;
     unsigned long long t_mma = 0, t_epi = 0, t_bar = 0, t_last = 0;
-    const bool stamp = (a.dbg & 8) != 0;
+    const bool stamp = IPDM_CONV_STAMPS && (a.dbg & 8) != 0;
     const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
     t_last = t_begin;
     // Epilogue addressing is VALU-free: buffer stores take ONE per-lane byte offset (fixed for the whole kernel) and a

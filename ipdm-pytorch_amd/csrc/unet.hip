@@ -769,7 +769,7 @@ size_t fixed_ws_bytes(const ipdm_unet *net, int B)
     size_t s = 0;
     s += align_up((size_t)net->topo.ted * 2 * sizeof(float), 256);              // emb tmp + silu(emb)
     s += align_up((size_t)(net->temb_rows ? net->temb_rows : 1) * sizeof(float), 256);   // bias_eff
-    s += 2 * align_up((size_t)B * net->max_ch * sizeof(float), 256);             // gn scale/shift
+    s += 2 * align_up(((size_t)B * net->max_ch + 64) * sizeof(float), 256);      // gn scale/shift (+ a K chunk of read-ahead)
     s += align_up(gn_partials_bytes(B, net->max_gn_groups), 256);
     return s;
 }
@@ -808,8 +808,8 @@ int run_forward(ipdm_unet *net, const float *d_x, int t, float *d_eps, int B, in
     float *emb_tmp = (float *)w; float *silu_emb = emb_tmp + net->topo.ted;
     w += align_up((size_t)net->topo.ted * 2 * sizeof(float), 256);
     net->bias_eff = (float *)w; w += align_up((size_t)(net->temb_rows ? net->temb_rows : 1) * sizeof(float), 256);
-    net->gn_scale = (float *)w; w += align_up((size_t)B * net->max_ch * sizeof(float), 256);
-    net->gn_shift = (float *)w; w += align_up((size_t)B * net->max_ch * sizeof(float), 256);
+    net->gn_scale = (float *)w; w += align_up(((size_t)B * net->max_ch + 64) * sizeof(float), 256);
+    net->gn_shift = (float *)w; w += align_up(((size_t)B * net->max_ch + 64) * sizeof(float), 256);
     net->gn_part = (double *)w;
     net->ws = (char *)d_ws + fixed;
     net->arena.reset(dry ? (size_t)1 << 46 : ws_bytes - fixed);
@@ -972,8 +972,8 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
         IPDM_HIP_CHECK(hipMalloc((void **)&d_be, Cin * sizeof(float)));
         IPDM_HIP_CHECK(hipMemcpy(d_g, gamma_host, Cin * sizeof(float), hipMemcpyHostToDevice));
         IPDM_HIP_CHECK(hipMemcpy(d_be, beta_host, Cin * sizeof(float), hipMemcpyHostToDevice));
-        IPDM_HIP_CHECK(hipMalloc((void **)&d_sc, (size_t)B * Cin * sizeof(float)));
-        IPDM_HIP_CHECK(hipMalloc((void **)&d_sh, (size_t)B * Cin * sizeof(float)));
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_sc, ((size_t)B * Cin + 64) * sizeof(float)));      // (+ a K chunk of read-ahead)
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_sh, ((size_t)B * Cin + 64) * sizeof(float)));
         IPDM_HIP_CHECK(hipMalloc((void **)&d_part, gn_partials_bytes(B, groups)));
         GnArgs g;
         g.x1 = d_x1; g.x2 = d_x2; g.C1 = C1; g.C2 = C2; g.B = B; g.HW = (long)Hs * Ws; g.groups = groups;
@@ -1035,8 +1035,8 @@ extern "C" int ipdm_op_conv_gn_conv(const float *d_x, int32_t C, int32_t B, int3
     if (!rc && bB_host) rc = dev(bB_host, CB * 4, (void **)&d_bB);
     if (!rc) rc = dev(gamma_host, CA * 4, (void **)&d_g);
     if (!rc) rc = dev(beta_host, CA * 4, (void **)&d_be);
-    if (!rc) rc = dev(nullptr, (size_t)B * CA * 4, (void **)&d_sc);
-    if (!rc) rc = dev(nullptr, (size_t)B * CA * 4, (void **)&d_sh);
+    if (!rc) rc = dev(nullptr, ((size_t)B * CA + 64) * 4, (void **)&d_sc);
+    if (!rc) rc = dev(nullptr, ((size_t)B * CA + 64) * 4, (void **)&d_sh);
     if (!rc) rc = dev(nullptr, gn_partials_bytes(B, groups), (void **)&d_part);
     ConvArgs a;
     a.x1 = d_x; a.x2 = nullptr; a.C1 = C; a.C2 = 0; a.B = B; a.Hs = H; a.Ws = W; a.H = H; a.W = W; a.upsample = 0;
@@ -1097,8 +1097,8 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     if (C2) { IPDM_HIP_CHECK(hipMalloc((void **)&d_x2, (size_t)B * C2 * H * W * 4)); ipdm_randn(d_x2, B, (int64_t)C2 * H * W, 2, 0, 0, nullptr); }
     IPDM_HIP_CHECK(hipMalloc((void **)&d_out, (size_t)B * Cout * Ho * Wo * 4));
     if (with_res) { IPDM_HIP_CHECK(hipMalloc((void **)&d_res, (size_t)B * Cout * Ho * Wo * 4)); ipdm_randn(d_res, B, (int64_t)Cout * Ho * Wo, 3, 0, 0, nullptr); }
-    IPDM_HIP_CHECK(hipMalloc((void **)&d_sc, (size_t)B * Cin * 4));
-    IPDM_HIP_CHECK(hipMalloc((void **)&d_sh, (size_t)B * Cin * 4));
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_sc, ((size_t)B * Cin + 64) * 4));
+    IPDM_HIP_CHECK(hipMalloc((void **)&d_sh, ((size_t)B * Cin + 64) * 4));
     IPDM_HIP_CHECK(hipMalloc((void **)&d_b, (size_t)Cout * 4));
     ipdm_randn(d_sc, 1, (int64_t)B * Cin, 4, 0, 0, nullptr);
     ipdm_randn(d_sh, 1, (int64_t)B * Cin, 5, 0, 0, nullptr);

@@ -1,11 +1,11 @@
 """A/B of two builds of libipdm_hip.so in ONE process, interleaved rounds (rule: perf deltas from interleaved rounds):
-   python tools/ab_lib.py ipdm-pytorch_amd/libipdm_hip.so ipdm-pytorch_amd/libipdm_hip_dpp.so"""
+   python tools/ab_lib.py <libA.so> <libB.so> [<libC.so> ...]      (percentages: time relative to A, negative = faster)"""
 import ctypes as C
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 torch.zeros(1, device="cuda")
-libs = [C.CDLL(os.path.abspath(p)) for p in sys.argv[1:3]]
+libs = [C.CDLL(os.path.abspath(p)) for p in sys.argv[1:]]
 for l in libs:
     l.ipdm_bench_conv2d.argtypes = [C.c_int32] * 11 + [C.POINTER(C.c_float)]
 CONVS = [  # B, C1, C2, H, W, Cout, ks, stride, act, res
@@ -23,5 +23,6 @@ for rnd in range(4):
 for c in CONVS:
     B, C1, C2, H, W, Co, ks, st, act, r = c
     fl = 2.0 * B * H * W * Co * (C1 + C2) * ks * ks
-    a, b = min(res[(c, 0)]), min(res[(c, 1)])
-    print("conv %-42s A %.3f ms %6.1f TF/s | B %.3f ms %6.1f TF/s | A/B %+.1f%%" % (c, a, fl / a / 1e9, b, fl / b / 1e9, 100 * (a / b - 1)))
+    best = [min(res[(c, i)]) for i in range(len(libs))]
+    print("conv %-42s A %.3f ms %6.1f TF/s | " % (c, best[0], fl / best[0] / 1e9) +
+          "  ".join("%s %+.1f%%" % (chr(66 + i - 1), 100 * (best[i] / best[0] - 1)) for i in range(1, len(libs))))
