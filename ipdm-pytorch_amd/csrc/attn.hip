@@ -192,35 +192,48 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
     const int bh = blockIdx.y;                      // sample*heads + head
     const int b = bh / heads, head = bh % heads;
     const float *qp = qkv + ((size_t)b * heads * 3 * D + (size_t)head * 3 * D) * T;
-    const float *kp = qp + (size_t)D * T;
-    const float *vp = qp + (size_t)2 * D * T;
     const int ntiles = (T + KV - 1) / KV;
     const int tps = (ntiles + zsplit - 1) / zsplit;
     const int it0 = blockIdx.z * tps, it1 = min(ntiles, it0 + tps);
 
     if (threadIdx.x >= 256) {
         // ------------------------------------------------------------------ producers
+        // VALU-free inside the tile loop (the MFMA waves leave a producer's vector ALU only their stall gaps): buffer
+        // loads take a per-thread byte offset that is fixed for the whole kernel plus a scalar offset per tile, LDS
+        // stores take one base register per stage plus immediates.  The scale is folded into Q (consumers), K is
+        // staged as it is.  Keys beyond T exist only in the last tile: their lanes get an out-of-range offset (= 0).
         const int tid = threadIdx.x - 256;
+        constexpr int NE = (D * KV) / 256;                  // elements of K (and of V) per thread per tile
+        const int s_l = tid % KV, c_l = tid / KV;           // element e of the thread: key s_l, channel c_l + 4 e
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)qp, 0, 3 * D * T * 4, 0x00020000);
+        int voff[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) voff[e] = ((c_l + (256 / KV) * e) * T + s_l) * 4;
+        const int k_base = s_l * KP + c_l, v_base = c_l * VP + s_l;       // + (256/KV) e  resp.  + (256/KV) e VP
         for (int it = it0; it < it1; ++it) {
             const int s0 = it * KV;
             float *k_lds = smem + (it & 1) * STAGE, *v_lds = k_lds + KV * KP;
-            float kr[(D * KV) / 256], vr[(D * KV) / 256];
+            const bool last = s0 + KV > T;                  // wave-uniform
+            float kr[NE], vr[NE];
+            if (!last) {
 #pragma unroll
-            for (int e = 0; e < (D * KV) / 256; ++e) {
-                const int idx = tid + e * 256;
-                const int c = idx / KV, s = idx % KV;
-                const bool ok = (s0 + s) < T;
-                const size_t g = (size_t)c * T + min(s0 + s, T - 1);
-                kr[e] = ok ? kp[g] : 0.0f;
-                vr[e] = ok ? vp[g] : 0.0f;
+                for (int e = 0; e < NE; ++e) {
+                    kr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[e], (D * T + s0) * 4, 0));
+                    vr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[e], (2 * D * T + s0) * 4, 0));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const int vo = s0 + s_l >= T ? 0x7fffffff : voff[e];
+                    kr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (D * T + s0) * 4, 0));
+                    vr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (2 * D * T + s0) * 4, 0));
+                }
             }
             // stage (it&1) was last read for tile it-2, which the consumers finished before the previous hand-over
 #pragma unroll
-            for (int e = 0; e < (D * KV) / 256; ++e) {
-                const int idx = tid + e * 256;
-                const int c = idx / KV, s = idx % KV;
-                k_lds[s * KP + c] = kr[e] * scale;
-                v_lds[c * VP + s] = vr[e];
+            for (int e = 0; e < NE; ++e) {
+                k_lds[k_base + (256 / KV) * e] = kr[e];
+                v_lds[v_base + (256 / KV) * e * VP] = vr[e];
             }
             __syncthreads();
         }
@@ -237,7 +250,7 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
     for (int qt = 0; qt < QT; ++qt) {
         const int t = t0 + qt * 32 + l31;
 #pragma unroll
-        for (int p = 0; p < HP; ++p) qreg[qt][p] = t < T ? qp[(size_t)(lh * HP + p) * T + t] * scale : 0.0f;
+        for (int p = 0; p < HP; ++p) qreg[qt][p] = t < T ? qp[(size_t)(lh * HP + p) * T + t] * (scale * scale) : 0.0f;   // both d^(-1/4) factors
     }
     constexpr int CB = D / 32;
     f32x16 o[QT][CB];

@@ -13,6 +13,9 @@ CONVS = [  # B, C1, C2, H, W, Cout, ks, stride, act, res
     (8, 128, 0, 228, 500, 128, 3, 1, 2, 1), (8, 128, 0, 512, 512, 128, 3, 1, 0, 0), (8, 256, 0, 64, 64, 256, 3, 1, 2, 1),
     (8, 256, 0, 64, 64, 768, 1, 1, 1, 0), (8, 128, 128, 228, 500, 128, 1, 1, 0, 0), (8, 128, 128, 228, 500, 128, 3, 1, 2, 0),
 ]
+ATTN = [(8, 4, 64, 7125), (8, 4, 64, 4096), (8, 4, 64, 1827), (8, 4, 64, 1024), (1, 4, 64, 4096)]
+for l in libs:
+    l.ipdm_bench_attention.argtypes = [C.c_int32] * 5 + [C.POINTER(C.c_float)]
 ms = C.c_float()
 res = {}
 for rnd in range(4):
@@ -25,4 +28,15 @@ for c in CONVS:
     fl = 2.0 * B * H * W * Co * (C1 + C2) * ks * ks
     best = [min(res[(c, i)]) for i in range(len(libs))]
     print("conv %-42s A %.3f ms %6.1f TF/s | " % (c, best[0], fl / best[0] / 1e9) +
+          "  ".join("%s %+.1f%%" % (chr(66 + i - 1), 100 * (best[i] / best[0] - 1)) for i in range(1, len(libs))))
+for rnd in range(4):
+    for c in ATTN:
+        for i, l in enumerate(libs):
+            assert l.ipdm_bench_attention(*c, 5, C.byref(ms)) == 0
+            res.setdefault((c, i), []).append(ms.value)
+for c in ATTN:
+    B, h, d, T = c
+    fl = 4.0 * B * h * T * T * d
+    best = [min(res[(c, i)]) for i in range(len(libs))]
+    print("attn %-42s A %.3f ms %6.1f TF/s | " % (c, best[0], fl / best[0] / 1e9) +
           "  ".join("%s %+.1f%%" % (chr(66 + i - 1), 100 * (best[i] / best[0] - 1)) for i in range(1, len(libs))))
