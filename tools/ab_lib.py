@@ -18,10 +18,11 @@ for l in libs:
     l.ipdm_bench_attention.argtypes = [C.c_int32] * 5 + [C.POINTER(C.c_float)]
 ms = C.c_float()
 res = {}
-for rnd in range(4):
+for rnd in range(2 * len(libs)):
     for c in CONVS:
-        for i, l in enumerate(libs):
-            assert l.ipdm_bench_conv2d(*c, 10, C.byref(ms)) == 0
+        for k in range(len(libs)):            # rotate the order: the first build after a shape change runs on cold caches
+            i = (k + rnd) % len(libs)
+            assert libs[i].ipdm_bench_conv2d(*c, 10, C.byref(ms)) == 0
             res.setdefault((c, i), []).append(ms.value)
 for c in CONVS:
     B, C1, C2, H, W, Co, ks, st, act, r = c
@@ -29,10 +30,11 @@ for c in CONVS:
     best = [min(res[(c, i)]) for i in range(len(libs))]
     print("conv %-42s A %.3f ms %6.1f TF/s | " % (c, best[0], fl / best[0] / 1e9) +
           "  ".join("%s %+.1f%%" % (chr(66 + i - 1), 100 * (best[i] / best[0] - 1)) for i in range(1, len(libs))))
-for rnd in range(4):
+for rnd in range(2 * len(libs)):
     for c in ATTN:
-        for i, l in enumerate(libs):
-            assert l.ipdm_bench_attention(*c, 5, C.byref(ms)) == 0
+        for k in range(len(libs)):
+            i = (k + rnd) % len(libs)
+            assert libs[i].ipdm_bench_attention(*c, 5, C.byref(ms)) == 0
             res.setdefault((c, i), []).append(ms.value)
 for c in ATTN:
     B, h, d, T = c
