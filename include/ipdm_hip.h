@@ -188,6 +188,17 @@ int ipdm_op_conv_gn_conv(const float *d_x, int32_t C, int32_t B, int32_t H, int3
                          int32_t groups, const float *gamma_host, const float *beta_host, int32_t act,
                          const float *wB_host, const float *bB_host, int32_t CB, float *d_mid, float *d_out,
                          int32_t *fused_rows, void *stream);
+/* Test entry for the Upsample layer (Model/model.py Upsample: F.interpolate(scale 2, "nearest") + 3x3 conv) in the form the
+ * executor runs it: conv A over the 2x up-sampled d_x [B,C,Hs,Ws] (on wide layers as four 2x2-tap parity convolutions over
+ * the source grid with pre-added weights, output stored parity-planar; *used_up2 reports which), then
+ * GroupNorm(+SiLU) over cat(mid, d_skip) and conv B (ksB = 1 or 3) reading mid as stored.
+ *   wA_host [CA,C,3,3], wB_host [CB,CA+C2,ksB,ksB], gamma/beta [CA+C2] HOST; d_skip [B,C2,2Hs,2Ws] or NULL (C2 = 0);
+ *   d_mid [B,CA,2Hs,2Ws] (conv A's output as NCHW), d_out [B,CB,2Hs,2Ws]; act: 1 GN, 2 GN+SiLU. */
+int ipdm_op_up_conv_chain(const float *d_x, int32_t C, int32_t B, int32_t Hs, int32_t Ws, const float *wA_host,
+                          const float *bA_host, int32_t CA, const float *d_skip, int32_t C2, int32_t groups,
+                          const float *gamma_host, const float *beta_host, int32_t act, const float *wB_host,
+                          const float *bB_host, int32_t CB, int32_t ksB, float *d_mid, float *d_out,
+                          int32_t *used_up2, void *stream);
 /* AttentionBlock core (Model/model.py:148-153): d_qkv [B, heads*3*d, T] (per-head (q,k,v) chunks)
  * -> d_out [B, heads*d, T]. */
 int ipdm_op_attention(const float *d_qkv, float *d_out, int32_t B, int32_t heads, int32_t d, int32_t T,

@@ -408,6 +408,65 @@ size_t conv_split_ws_bytes(const ConvArgs &a)
 int conv_k_chunk() { return 8; }
 int conv_ws_k_chunk(int ks, int interleave) { return conv_sx_pieces(interleave) ? 16 : ((interleave && ks == 1) ? 32 : 8); }
 
+// Up-sampling convolution (nearest 2x, then 3x3, zero padding 1): output pixel (2y + a, 2x + b) reads the source pixels
+// (y + i + a - 1, x + j + b - 1), i, j in {0, 1}; the 3x3 taps that land on the same source pixel are
+//   a = 0:  i = 0 <- ky {0},     i = 1 <- ky {1, 2}          a = 1:  i = 0 <- ky {0, 1},   i = 1 <- ky {2}
+// (the same for b / kx).  Their sum (in double, rounded once) is the 2x2 weight of that parity.
+void conv_pack_weights_up2(const float *w, int Cout, int Cin, int interleave, std::vector<float> &packed)
+{
+    packed.clear();
+    std::vector<float> w2((size_t)Cout * Cin * 4), one;
+    for (int par = 0; par < 4; ++par) {
+        const int a = par >> 1, b = par & 1;
+        for (size_t oc = 0; oc < (size_t)Cout * Cin; ++oc)
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) {
+                    const int ky0 = a == 0 ? (i == 0 ? 0 : 1) : (i == 0 ? 0 : 2), ky1 = a == 0 ? (i == 0 ? 0 : 2) : (i == 0 ? 1 : 2);
+                    const int kx0 = b == 0 ? (j == 0 ? 0 : 1) : (j == 0 ? 0 : 2), kx1 = b == 0 ? (j == 0 ? 0 : 2) : (j == 0 ? 1 : 2);
+                    double acc = 0.0;
+                    for (int ky = ky0; ky <= ky1; ++ky)
+                        for (int kx = kx0; kx <= kx1; ++kx) acc += (double)w[oc * 9 + ky * 3 + kx];
+                    w2[oc * 4 + i * 2 + j] = (float)acc;
+                }
+        int cin_pad, cout_pad;
+        conv_pack_weights(w2.data(), Cout, Cin, 2, interleave, one, cin_pad, cout_pad);
+        packed.insert(packed.end(), one.begin(), one.end());
+    }
+}
+
+bool conv_planar_ok(const ConvArgs &a)
+{
+    if (a.upsample || (a.Hs & 1) || (a.Ws & 1)) return false;
+    if (conv_sx_pieces(a.w_interleave)) return false;
+    if (a.w_interleave) return conv_ws_planar_ok(a);                    // the wave-specialised kernels (conv_ws.hip)
+    static const bool no_direct = getenv("IPDM_CONV_NO_DIRECT") != nullptr;
+    static const bool no_planar = getenv("IPDM_DIRECT_NO_PLANAR") != nullptr;
+    return !no_direct && !no_planar && conv_direct_eligible(a);
+}
+
+namespace {
+__global__ void __launch_bounds__(256) planar_to_linear_kernel(const float *__restrict__ src, float *__restrict__ dst, long planes, int H, int W)
+{
+    const long total = planes * H * W;
+    const int h2 = H >> 1, w2 = W >> 1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)(i / W % H);
+        const long pl = i / ((long)H * W);
+        dst[i] = src[pl * H * W + ((long)((y & 1) * 2 + (x & 1)) * h2 + (y >> 1)) * w2 + (x >> 1)];
+    }
+}
+}  // namespace
+
+int planar_to_linear_launch(const float *src, float *dst, long planes, int H, int W, hipStream_t st)
+{
+    IPDM_REQUIRE(!(H & 1) && !(W & 1), "planar_to_linear: odd size %dx%d", H, W);
+    const long total = planes * H * W;
+    int g = (int)((total + 1023) / 1024); if (g > 8192) g = 8192; if (g < 1) g = 1;
+    hipLaunchKernelGGL(planar_to_linear_kernel, dim3(g), dim3(256), 0, st, src, dst, planes, H, W);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
 int conv_weight_interleave(int Cout, int ks, int stride)
 {
     static const bool legacy = getenv("IPDM_CONV_LEGACY") != nullptr;

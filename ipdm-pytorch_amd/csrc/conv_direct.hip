@@ -56,7 +56,11 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
 {
     constexpr int DIN_H = DT_H + KS - 1, DIN_W = DT_W + KS - 1, DIN_CH = DIN_H * DIN_P, TAPS = KS * KS, PAD = KS / 2;
     __shared__ __attribute__((aligned(16))) float in_lds[DKC * DIN_CH];
-    __shared__ __attribute__((aligned(16))) float w_lds[DKC * TAPS * CO];
+    // weights: wave-uniform addresses in the constant address space -> scalar loads; a cout pair is the SGPR operand of
+    // one v_pk_fma_f32 (as LDS broadcast reads they cost 9*CO/4 ds_read_b128 per channel and wave, and the LDS pipe --
+    // one per CU, shared by the 4 SIMDs -- was the bound of this loop, not the VALU)
+    typedef const __attribute__((address_space(4))) float cfloat;
+    cfloat *wk = (cfloat *)(unsigned long long)a.w;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const int n = blockIdx.z;
@@ -72,7 +76,7 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
 
     // staging descriptors: element e of the tile = (row r, col c) for every channel of a chunk
     constexpr int NSP = (DIN_H * DIN_W + 255) / 256;
-    int sp_src[NSP], sp_dst[NSP];
+    int sp_src[NSP], sp_srcp[NSP], sp_dst[NSP];      // sp_srcp: the same element inside a parity-planar x1 (ConvArgs::x1_planar)
     bool sp_ok[NSP];
 #pragma unroll
     for (int j = 0; j < NSP; ++j) {
@@ -86,6 +90,7 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
             sx = min((int)floorf((float)sx * a.scale_x), a.Ws - 1);
         }
         sp_src[j] = sy * a.Ws + sx;
+        sp_srcp[j] = a.x1_planar ? (((sy & 1) * 2 + (sx & 1)) * (a.Hs >> 1) + (sy >> 1)) * (a.Ws >> 1) + (sx >> 1) : sp_src[j];
         sp_dst[j] = e < DIN_H * DIN_W ? r * DIN_P + c : -1;
     }
 
@@ -97,10 +102,15 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
 #pragma unroll
         for (int c = 0; c < DKC; ++c) {
             const int cg = min(c0 + c, Ctot - 1);          // channels beyond Cin re-read the last one; they are not consumed
-            const float *src = cg < a.C1 ? a.x1 + ((size_t)n * a.C1 + cg) * src_plane
-                                         : a.x2 + ((size_t)n * a.C2 + (cg - a.C1)) * src_plane;
+            if (cg < a.C1) {                               // (uniform)
+                const float *src = a.x1 + ((size_t)n * a.C1 + cg) * src_plane;
 #pragma unroll
-            for (int j = 0; j < NSP; ++j) raw[c][j] = src[sp_src[j]];
+                for (int j = 0; j < NSP; ++j) raw[c][j] = src[sp_srcp[j]];
+            } else {
+                const float *src = a.x2 + ((size_t)n * a.C2 + (cg - a.C1)) * src_plane;
+#pragma unroll
+                for (int j = 0; j < NSP; ++j) raw[c][j] = src[sp_src[j]];
+            }
         }
 #pragma unroll
         for (int c = 0; c < DKC; ++c) {
@@ -118,11 +128,6 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
                 }
             }
         }
-        // weights: packed [Cin_pad8][9][cout_pad] (plain layout), cout_pad >= CO
-        for (int e = tid; e < kc * TAPS * CO; e += 256) {
-            const int co = e % CO, rest = e / CO;          // rest = c*TAPS + tap
-            w_lds[e] = a.w[((size_t)c0 * TAPS + rest) * a.cout_pad + co];
-        }
         __syncthreads();
         for (int c = 0; c < kc; ++c) {
             const float *ip = in_lds + c * DIN_CH + ty * DIN_P + tx * 4;
@@ -134,14 +139,11 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
                 const float iv[6] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1]};
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
-                    const float *wp = w_lds + (c * TAPS + ky * KS + kx) * CO;
+                    // packed [Cin_pad8][taps][cout_pad] (plain layout), cout_pad >= CO
+                    cfloat *wp = wk + ((size_t)(c0 + c) * TAPS + ky * KS + kx) * a.cout_pad;
                     f32x2 wv[CO / 2];
 #pragma unroll
-                    for (int q = 0; q < CO / 4; ++q) {
-                        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wp + q * 4);      // broadcast read
-                        wv[2 * q] = f32x2{w4[0], w4[1]};
-                        wv[2 * q + 1] = f32x2{w4[2], w4[3]};
-                    }
+                    for (int q = 0; q < CO / 2; ++q) wv[q] = f32x2{wp[2 * q], wp[2 * q + 1]};
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -242,6 +244,7 @@ int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
 {
     IPDM_REQUIRE(!a.stats || a.stats_rows == conv_direct_stats_rows(a), "conv2d: statistics rows %d != %d", a.stats_rows,
                  conv_direct_stats_rows(a));
+    IPDM_REQUIRE(!a.x1_planar || (!a.upsample && !(a.Hs & 1) && !(a.Ws & 1)), "conv2d: parity-planar input of odd size %dx%d", a.Hs, a.Ws);
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 31) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 31),
                  "conv2d: per-sample tensor exceeds 32-bit offsets");
     if (a.ksize == 1) {     // the 1x1 shortcuts of the narrow levels: pure streaming

@@ -144,10 +144,11 @@ __device__ inline float sum_lanes_half(float x)         // over all 32 lanes of 
 }
 #undef IPDM_DPP_F
 
-template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4>
+template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4, bool PLANAR>
 __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
 {
     using T = WsTile<KS, STRIDE, MB, NB, KC, IL, PBW>;
+    constexpr bool UP2 = KS == 2;      // the up-sampling convolution's parity form (below)
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     // ---- static tile schedule: at step k the G workgroups cover tiles [kG,(k+1)G); the workgroups of one XCD
@@ -165,7 +166,12 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     // K split (ConvArgs::ksplit > 1: layers with too few tiles to fill the chip): a "tile" of the schedule is then one
     // slice of the channel chunks of an output tile, and its sums go to slice ks of a partial buffer (no bias, residual
     // or statistics here: splitk_combine adds the slices in a fixed order and applies them)
-    const int nchunks = (Ctot + KC - 1) / KC / a.ksplit;
+    // up2 (ConvArgs::up2, KS = 2): the convolution of a 2x nearest up-sampled image, evaluated on the SOURCE grid as four
+    // 2x2-tap convolutions, one per output parity (a, b) = (row & 1, col & 1): the 3x3 taps that fall on the same source
+    // pixel were added up when the weights were packed (4 instead of 9 multiply-adds per output).  The parity is the `ks`
+    // digit of the tile; its weights are slab `ks`, its window starts at (oy0 + a - 1, ox0 + b - 1), and its outputs go
+    // to plane `ks` of the parity-planar output [n][cout][a][b][Ho][Wo] (readers: ConvArgs::x1_planar).
+    const int nchunks = (Ctot + KC - 1) / KC / (UP2 ? 1 : a.ksplit);
     const int S = n_my * nchunks;                  // chunks in this workgroup's stream
     const int plane_bytes = a.Hs * a.Ws * 4;
     if (threadIdx.x >= 256) {
@@ -181,8 +187,8 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
             w_voff[e] = v4 < T::W_TILE / 4 ? (row * a.cout_pad + col4 * 4) * 4 : OOB;
         }
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)a.w, 0, ((Ctot + KC - 1) / KC * KC) * T::TAPS * a.cout_pad * 4, 0x00020000);
-        int in_voff[T::SP];
+            (void *)a.w, 0, ((Ctot + KC - 1) / KC * KC) * T::TAPS * a.cout_pad * 4 * (UP2 ? 4 : 1), 0x00020000);
+        int in_voff[T::SP], in_voffp[T::SP];      // in_voffp: the same elements inside a parity-planar x1
         bool in_ok[T::SP];
         TileId t = {0, 0, 0, 0};
         bool border = false;
@@ -194,7 +200,8 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 const int k = s / nchunks, ch = s - k * nchunks;
                 if (ch == 0) {      // new tile: spatial descriptors (the same for every channel chunk of the tile)
                     t = decode_tile<T::TH, T::TW, T::BN>(a, tile_of(k));
-                    const int iy0 = t.oy0 * STRIDE - KS / 2, ix0 = t.ox0 * STRIDE - KS / 2;
+                    const int iy0 = t.oy0 * STRIDE - (KS == 2 ? 1 - (t.ks >> 1) : KS / 2);
+                    const int ix0 = t.ox0 * STRIDE - (KS == 2 ? 1 - (t.ks & 1) : KS / 2);
                     border = iy0 < 0 || ix0 < 0 || iy0 + T::IN_ROWS > a.H || ix0 + T::IN_COLS > a.W;
 #pragma unroll
                     for (int j = 0; j < T::SP; ++j) {
@@ -208,9 +215,10 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                             sx = min((int)floorf((float)sx * a.scale_x), a.Ws - 1);
                         }
                         in_voff[j] = in_ok[j] ? (sy * a.Ws + sx) * 4 : OOB;      // padding / idle slots read 0
+                        if (PLANAR) in_voffp[j] = in_ok[j] ? ((((sy & 1) * 2 + (sx & 1)) * (a.Hs >> 1) + (sy >> 1)) * (a.Ws >> 1) + (sx >> 1)) * 4 : OOB;
                     }
                 }
-                const int c0 = (t.ks * nchunks + ch) * KC;
+                const int c0 = ((UP2 ? 0 : t.ks * nchunks) + ch) * KC;
                 const int nvalid = min(KC, Ctot - c0);
                 float *ib = lds + (s & 1) * T::BUF;
                 // a chunk never straddles the two concatenated sources (launcher: C1 % KC == 0 when C2 > 0)
@@ -222,18 +230,23 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 const int cs0 = from1 ? c0 : c0 - a.C1;
                 // weights first (they need no transform and go to LDS as soon as they land), then the raw input tile
                 f32x4 w_reg[T::W_VEC];
-                const int w_soff = (c0 * T::TAPS * a.cout_pad + t.co0 / T::LW * T::LW) * 4;   // the whole interleave group of the tile
+                const int w_row0 = UP2 ? t.ks * (nchunks * KC) : 0;                         // up2: the parity's weight slab
+                const int w_soff = ((w_row0 + c0) * T::TAPS * a.cout_pad + t.co0 / T::LW * T::LW) * 4;   // the whole interleave group of the tile
 #pragma unroll
                 for (int e = 0; e < T::W_VEC; ++e)
                     w_reg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[e], w_soff, 0));
                 float raw[KC][T::SP];
+                auto load_raw = [&](const int (&voff)[T::SP]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int c = 0; c < KC; ++c) {
-                    // channels beyond Cin re-read the last real channel (in-range scalar offset); their weights are zero
-                    const int soff = (cs0 + min(c, nvalid - 1)) * plane_bytes;
+                    for (int c = 0; c < KC; ++c) {
+                        // channels beyond Cin re-read the last real channel (in-range scalar offset); their weights are zero
+                        const int soff = (cs0 + min(c, nvalid - 1)) * plane_bytes;
 #pragma unroll
-                    for (int j = 0; j < T::SP; ++j) raw[c][j] = bload(x_rsrc, in_voff[j], soff);
-                }
+                        for (int j = 0; j < T::SP; ++j) raw[c][j] = bload(x_rsrc, voff[j], soff);
+                    }
+                };
+                if (PLANAR && from1) load_raw(in_voffp);      // (uniform branch: a select per load would be VALU)
+                else load_raw(in_voff);
                 // stage (s&1) was last read by chunk s-2, which the consumers finished before the previous hand-over
 #pragma unroll
                 for (int e = 0; e < T::W_VEC; ++e)
@@ -316,7 +329,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
     // Epilogue addressing is VALU-free: buffer stores take ONE per-lane byte offset (fixed for the whole kernel) and a
     // scalar offset per (cout, row); anything outside the sample's [Cout][Ho][Wo] block is dropped by the range check.
     const int swave = __builtin_amdgcn_readfirstlane(wave);
-    const int out_plane = a.Ho * a.Wo;
+    const int out_plane = a.Ho * a.Wo * (UP2 ? 4 : 1);      // channel stride of the output (up2: 4 parity planes)
     const int lane_off = (lk * 4 * out_plane + ly * a.Wo + lx) * 4;      // lane part: cout half, block row, block column
     // bias (conv bias + time-embedding projection) is added by one MFMA per accumulator after the last K chunk; the MB
     // bias values of the NEXT tile are fetched right after, a whole tile ahead of their use.
@@ -405,7 +418,8 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
             // ---- tile epilogue: (+ residual) -> NCHW stores, 32 consecutive pixels per half-wave; the stores drain
             //      while the next tile is multiplied
             const TileId t = decode_tile<T::TH, T::TW, T::BN>(a, tile_of(k));
-            const size_t sample = ((size_t)t.ks * a.B + t.n) * a.Cout * out_plane;
+            const size_t sample = ((size_t)(UP2 ? 0 : t.ks) * a.B + t.n) * a.Cout * out_plane;
+            const int par_off = UP2 ? t.ks * a.Ho * a.Wo * 4 : 0, par_row = UP2 ? t.ks * a.Ho : 0;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * out_plane * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0, a.Cout * out_plane * 4, 0x00020000);
             // per-lane offset: lane part, or out of range for columns beyond Wo / rows beyond Ho (dropped by the range
@@ -416,7 +430,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
             for (int q = 0; q < NB; ++q) {
                 const int oy = t.oy0 + (swave * NB + q) * PBH;          // first row of the block; the lane adds ly
                 voffq[q] = (t.ox0 + lx < a.Wo && oy + ly < a.Ho) ? lane_off : OOB;
-                rowq[q] = (min(oy, a.Ho - 1) * a.Wo + t.ox0) * 4;     // scalar offsets stay in range; the lanes are killed above
+                rowq[q] = (min(oy, a.Ho - 1) * a.Wo + t.ox0) * 4 + par_off;     // scalar offsets stay in range; the lanes are killed above
             }
             // one row of per-cout partial sums {sum, sum of squares} of block row q: staged [cout][2] in LDS by the lanes
             // that own a cout, read back as contiguous runs (DS operations of one wave execute in order, so the staging
@@ -428,7 +442,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                 const float *sb = lds + 2 * T::BUF + swave * 256;
                 const int oy = t.oy0 + (swave * NB + q) * PBH;
                 if (oy < a.Ho && lane * 2 < T::BN) {
-                    float *dst = a.stats + (((size_t)t.n * a.stats_rows + (size_t)oy * a.tiles_x + t.ox0 / T::TW) * a.Cout + t.co0) * 2;
+                    float *dst = a.stats + (((size_t)t.n * a.stats_rows + (size_t)(par_row + oy) * a.tiles_x + t.ox0 / T::TW) * a.Cout + t.co0) * 2;
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(sb + lane * 4);       // couts 2 lane, 2 lane + 1
                     if (!PARTIAL) *reinterpret_cast<f32x4 *>(dst + lane * 4) = v;
                     else {
@@ -607,7 +621,7 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
 
 int num_cus() { return device_cu_count(); }
 
-template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4>
+template <int KS, int STRIDE, int MB, int NB, int KC, int IL, int PBW, bool VEC4, bool PLANAR = false>
 int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
 {
     using T = WsTile<KS, STRIDE, MB, NB, KC, IL, PBW>;
@@ -621,24 +635,31 @@ int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
     a.tiles_y = cdiv(a.Ho, T::TH);
     a.co_tiles = cdiv(a.Cout, T::BN);
     IPDM_REQUIRE(a.C2 == 0 || a.C1 % KC == 0, "conv2d: concat split %d not a multiple of the K chunk %d", a.C1, KC);
+    IPDM_REQUIRE((KS == 2) == (a.up2 != 0), "conv2d: 2x2 taps are the up-sampling convolution's");
+    IPDM_REQUIRE(PLANAR == (a.x1_planar != 0), "conv2d: this kernel variant does not read parity-planar inputs");
+    IPDM_REQUIRE(!a.x1_planar || (!a.upsample && !(a.Hs & 1) && !(a.Ws & 1)), "conv2d: parity-planar input of odd size %dx%d", a.Hs, a.Ws);
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29) &&
-                     (long)a.Cout * a.Ho * a.Wo < (1L << 29) &&
-                     (long)((a.C1 + a.C2 + KC - 1) / KC * KC) * T::TAPS * a.cout_pad < (1L << 29),
+                     (long)a.Cout * a.Ho * a.Wo * (a.up2 ? 4 : 1) < (1L << 29) &&
+                     (long)((a.C1 + a.C2 + KC - 1) / KC * KC) * T::TAPS * a.cout_pad * (a.up2 ? 4 : 1) < (1L << 29),
                  "conv2d: per-sample tensor exceeds the 2 GiB buffer-addressing range");
     if (a.ksplit < 1) a.ksplit = 1;
-    IPDM_REQUIRE(((a.C1 + a.C2 + KC - 1) / KC) % a.ksplit == 0 && (a.ksplit == 1 || (!a.bias && !a.res && !a.stats)),
-                 "conv2d: bad K split %d", a.ksplit);
+    if (a.up2) {
+        IPDM_REQUIRE(!a.res && !a.C2 && !a.upsample && a.H == a.Ho && a.W == a.Wo, "conv2d: bad up-sampling convolution");
+        a.ksplit = 4;       // the parity is the tile's `ks` digit
+    } else
+        IPDM_REQUIRE(((a.C1 + a.C2 + KC - 1) / KC) % a.ksplit == 0 && (a.ksplit == 1 || (!a.bias && !a.res && !a.stats)),
+                     "conv2d: bad K split %d", a.ksplit);
     const long ntiles = (long)a.tiles_x * a.tiles_y * a.co_tiles * a.B * a.ksplit;
     IPDM_REQUIRE(ntiles < (1L << 31), "conv2d: too many tiles");
     const int cus = num_cus();
     int G = (int)(ntiles < cus ? ntiles : cus);
     G = (G + 7) / 8 * 8;
-    IPDM_REQUIRE(!a.stats || a.stats_rows == a.tiles_x * a.Ho, "conv2d: statistics rows %d != %d", a.stats_rows,
-                 a.tiles_x * a.Ho);
-    if (int rc = ensure_dynamic_lds((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>, LDS_TOTAL)) return rc;
+    IPDM_REQUIRE(!a.stats || a.stats_rows == a.tiles_x * a.Ho * (a.up2 ? 4 : 1), "conv2d: statistics rows %d != %d", a.stats_rows,
+                 a.tiles_x * a.Ho * (a.up2 ? 4 : 1));
+    if (int rc = ensure_dynamic_lds((const void *)conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4, PLANAR>, LDS_TOTAL)) return rc;
     const bool prof = prof_enabled();
     if (prof) prof_before(prof_cls, st);
-    hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4>), dim3((unsigned)G), dim3(512), LDS_TOTAL, st, a, (int)ntiles);
+    hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4, PLANAR>), dim3((unsigned)G), dim3(512), LDS_TOTAL, st, a, (int)ntiles);
     if (prof) prof_after(prof_cls, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
@@ -651,7 +672,12 @@ template <int KS, int STRIDE, int MB, int NB, int KC, int IL = MB, int PBW = 32>
 int launch_ws(const ConvArgs &a, hipStream_t st, int prof_cls)
 {
     static const bool strict = getenv("IPDM_CONV_VEC4_STRICT") != nullptr;     // A/B: rows of whole 4-pixel runs only, as in round 1
-    if ((!strict || (a.Wo & 3) == 0) && a.Cout % (32 * MB) == 0) return launch_ws_v<KS, STRIDE, MB, NB, KC, IL, PBW, true>(a, st, prof_cls);
+    if ((!strict || (a.Wo & 3) == 0) && a.Cout % (32 * MB) == 0) {
+        if constexpr (STRIDE == 1 && KS != 2) {       // readers of an up2 convolution's parity-planar output (conv_ws_planar_ok)
+            if (a.x1_planar) return launch_ws_v<KS, STRIDE, MB, NB, KC, IL, PBW, true, true>(a, st, prof_cls);
+        }
+        return launch_ws_v<KS, STRIDE, MB, NB, KC, IL, PBW, true>(a, st, prof_cls);
+    }
     return launch_ws_v<KS, STRIDE, MB, NB, KC, IL, PBW, false>(a, st, prof_cls);
 }
 
@@ -690,7 +716,7 @@ static int ws_tile_couts(const ConvArgs &a)
 int conv_ws_split(const ConvArgs &a)
 {
     static const bool off = getenv("IPDM_CONV_NO_SPLITK") != nullptr;
-    if (off || !a.w_interleave || a.w_interleave > 4) return 1;
+    if (off || !a.w_interleave || a.w_interleave > 4 || conv_up2_eligible(a)) return 1;
     const long per_sample = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128);
     if (per_sample > 16) return 1;
     const int nch = cdiv(a.C1 + a.C2, a.ksize == 1 ? 32 : 8);
@@ -701,8 +727,25 @@ int conv_ws_split(const ConvArgs &a)
     return best;
 }
 
+// which launches of this file can read x1 parity-planar: the stride-1 kernels with whole cout tiles (launch_ws)
+bool conv_ws_planar_ok(const ConvArgs &a)
+{
+    static const bool strict = getenv("IPDM_CONV_VEC4_STRICT") != nullptr;
+    return (a.w_interleave == 2 || a.w_interleave == 4) && a.stride == 1 && (a.ksize == 1 || a.ksize == 3) &&
+           a.Cout % (32 * a.w_interleave) == 0 && (!strict || (a.Wo & 3) == 0) && !conv_up2_eligible(a);
+}
+
+// the up-sampling convolution as four parity convolutions (ConvArgs::w_up2): exact 2x nearest, wide layers, no prologue
+bool conv_up2_eligible(const ConvArgs &a)
+{
+    static const bool off = getenv("IPDM_CONV_NO_UP2") != nullptr;
+    return !off && a.w_up2 && (a.w_interleave == 2 || a.w_interleave == 4) && a.ksize == 3 && a.stride == 1 && a.C2 == 0 &&
+           a.act == 0 && !a.res && a.H == 2 * a.Hs && a.W == 2 * a.Ws && a.Ho == a.H && a.Wo == a.W;
+}
+
 int conv_ws_stats_rows(const ConvArgs &a)
 {
+    if (conv_up2_eligible(a)) return 4 * a.Hs * cdiv(a.Ws, 32);
     if (a.split_ws && conv_ws_split(a) > 1) return cdiv((long)a.Ho * a.Wo, SPLIT_PIX);
     return a.Ho * cdiv(a.Wo, 32);      // one row per pixel row and 32-pixel tile column: independent of the tile variant
 }
@@ -748,6 +791,13 @@ static int conv2d_ws_dispatch(const ConvArgs &a, hipStream_t st);
 // conv_weight_interleave / conv_pack_weights).
 int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
 {
+    if (conv_up2_eligible(a)) {
+        ConvArgs k = a;
+        k.up2 = 1; k.w = a.w_up2; k.ksize = 2; k.upsample = 0; k.H = k.Ho = a.Hs; k.W = k.Wo = a.Ws; k.split_ws = nullptr; k.ksplit = 1;
+        // (16-channel chunks -- 16k instead of 8k cycles of MFMA per hand-over -- measured 0.7 % slower per forward)
+        if (a.w_interleave == 4) return launch_ws<2, 1, 4, 2, 8>(k, st, 0);
+        return launch_ws<2, 1, 2, 4, 8>(k, st, 0);
+    }
     const int S = a.split_ws ? conv_ws_split(a) : 1;
     if (S == 1) return conv2d_ws_dispatch(a, st);
     ConvArgs k = a;

@@ -308,7 +308,9 @@ namespace {
 
 // w_t: the same weights with the two kernel axes swapped (3x3 only): what the convolution needs when the executor runs
 // a forward on spatially TRANSPOSED activations (run_forward: orientation)
-struct ConvP { float *w = nullptr; float *w_t = nullptr; float *b = nullptr; int cin = 0, cout = 0, ks = 0, cout_pad = 0, interleave = 0; };
+// w_up2 / w_up2_t: the Upsample convolutions' parity form (conv_pack_weights_up2), null elsewhere
+struct ConvP { float *w = nullptr; float *w_t = nullptr; float *b = nullptr; int cin = 0, cout = 0, ks = 0, cout_pad = 0, interleave = 0;
+               float *w_up2 = nullptr, *w_up2_t = nullptr; };
 struct NormP { float *g = nullptr, *b = nullptr; int ch = 0, groups = 0; };
 struct ResP { NormP n1, n2; ConvP c1, c2, sc; bool has_sc = false; int bias_off = 0; };   // bias_off into bias_eff
 struct AttnP { NormP n; ConvP qkv, proj; };
@@ -354,7 +356,8 @@ struct Arena {
 // ConvArgs::stats); a materialised channel concat refers to the rows of its two sources (nst = 2).  nst = 0: none.
 struct StatRef { size_t off = 0; int rows = 0, C = 0; };
 struct Tensor { size_t off = (size_t)-1; size_t bytes = 0; int C = 0, H = 0, W = 0; int refs = 0; bool external = false; const float *ext = nullptr;
-                size_t st_off = (size_t)-1, st_bytes = 0; StatRef st[2]; int nst = 0; };
+                size_t st_off = (size_t)-1, st_bytes = 0; StatRef st[2]; int nst = 0;
+                bool planar = false; };      // stored parity-planar [B][C][2][2][H/2][W/2]: the output of an up2 convolution
 
 }  // namespace
 
@@ -417,7 +420,7 @@ struct WeightMap {
 };
 
 int make_conv(ipdm_unet *net, const WeightMap &wm, const std::string &wname, const std::string &bname, int cout, int cin,
-              int ks, ConvP &out, int stride = 1)
+              int ks, ConvP &out, int stride = 1, bool up = false)
 {
     const float *w = wm.get(wname);
     IPDM_REQUIRE(w, "unet_create: missing parameter %s", wname.c_str());
@@ -437,6 +440,12 @@ int make_conv(ipdm_unet *net, const WeightMap &wm, const std::string &wname, con
         conv_pack_weights(wt.data(), cout, cin, ks, out.interleave, packed, cin_pad, cout_pad);
         rc = upload(net, packed.data(), packed.size(), &out.w_t);
         if (rc) return rc;
+        if (up && (out.interleave == 2 || out.interleave == 4)) {      // Upsample: the parity form of both orientations
+            conv_pack_weights_up2(w, cout, cin, out.interleave, packed);
+            if ((rc = upload(net, packed.data(), packed.size(), &out.w_up2))) return rc;
+            conv_pack_weights_up2(wt.data(), cout, cin, out.interleave, packed);
+            if ((rc = upload(net, packed.data(), packed.size(), &out.w_up2_t))) return rc;
+        }
     }
     out.b = nullptr;
     if (!bname.empty()) {
@@ -504,7 +513,7 @@ extern "C" int ipdm_unet_create(const ipdm_unet_cfg *cfg, const float *const *we
         switch (l.kind) {
             case L_CONV: r = make_conv(net, wm, p + ".weight", p + ".bias", l.cout, l.cin, 3, net->convs[p]); break;
             case L_DOWN: r = make_conv(net, wm, p + ".op.weight", p + ".op.bias", l.cout, l.cin, 3, net->convs[p], 2); break;
-            case L_UP: r = make_conv(net, wm, p + ".conv.weight", p + ".conv.bias", l.cout, l.cin, 3, net->convs[p]); break;
+            case L_UP: r = make_conv(net, wm, p + ".conv.weight", p + ".conv.bias", l.cout, l.cin, 3, net->convs[p], 1, true); break;
             case L_RES: {
                 ResP &rp = net->res[p];
                 if ((r = make_norm(net, wm, p + ".conv1.0", l.cin, rp.n1))) break;
@@ -591,6 +600,16 @@ struct Fwd {
         }
     }
 
+    // a parity-planar tensor for a reader that takes NCHW only: returns a converted copy (caller releases), or null when
+    // t is NCHW already
+    Tensor *linear_copy(const Tensor *t)
+    {
+        if (!t || !t->planar) return nullptr;
+        Tensor *o = make(t->C, t->H, t->W);
+        if (!rc && !net->dry) rc = planar_to_linear_launch(ptr(t), wptr(o), (long)net->B * t->C, t->H, t->W, net->st);
+        return o;
+    }
+
     void gn(const Tensor *x1, const Tensor *x2, const NormP &np)
     {
         if (rc || net->dry) return;
@@ -635,6 +654,18 @@ struct Fwd {
         // (shape fields first: the statistics geometry depends on the kernel the dispatcher picks, in dry runs too)
         a.C1 = x1->C; a.C2 = x2 ? x2->C : 0; a.B = net->B; a.Cout = cp.cout; a.ksize = cp.ks; a.stride = stride; a.Ho = Ho; a.Wo = Wo;
         a.w_interleave = cp.interleave; a.cout_pad = cp.cout_pad;
+        a.Hs = x1->H; a.Ws = x1->W; a.H = H; a.W = W; a.upsample = (H != x1->H || W != x1->W); a.act = act; a.res = res ? (const float *)(uintptr_t)256 : nullptr;
+        a.w_up2 = net->transposed ? cp.w_up2_t : cp.w_up2;
+        // parity-planar sources (outputs of up2 convolutions): x1 of the kernels that can read them, converted otherwise
+        Tensor *lin1 = nullptr, *lin2 = linear_copy(x2), *linr = linear_copy(res);
+        if (x1->planar && !conv_planar_ok(a)) lin1 = linear_copy(x1);
+        if (lin1) x1 = lin1;
+        if (lin2) x2 = lin2;
+        if (linr) res = linr;
+        a.x1_planar = x1->planar ? 1 : 0;
+        struct LinGuard { Fwd &f; Tensor *a, *b, *c; ~LinGuard() { if (a) f.release(a); if (b) f.release(b); if (c) f.release(c); } } lin_guard{*this, lin1, lin2, linr};
+        if (conv_up2_eligible(a) && !ext_out) o->planar = true;
+        else a.w_up2 = nullptr;
         // layers with too few tiles to fill the chip are split along K into a scratch buffer (conv_ws.hip)
         const size_t split_bytes = conv_split_ws_bytes(a);
         size_t split_off = (size_t)-1;
@@ -683,6 +714,10 @@ struct Fwd {
         if (rp.has_sc) { sc = conv(x1, x2, rp.sc, 1, 0, rp.sc.b, nullptr, H, W); resid = sc; }
         else if (x2) {   // identity shortcut over a concatenated input: materialise the concat
             sc = make(x1->C + x2->C, H, W);
+            Tensor *l1 = linear_copy(x1), *l2 = linear_copy(x2);
+            struct G { Fwd &f; Tensor *a, *b; ~G() { if (a) f.release(a); if (b) f.release(b); } } g_{*this, l1, l2};
+            if (l1) x1 = l1;
+            if (l2) x2 = l2;
             if (!rc && !net->dry) {
                 const long total = (long)net->B * (x1->C + x2->C) * H * W;
                 int g = cdiv(total, 1024); if (g > 4096) g = 4096;
@@ -735,11 +770,14 @@ struct Fwd {
         if (x2 && (x1->C % align) != 0) {
             // the conv kernel walks K in chunks that must not straddle the two sources: materialise torch.cat
             cat = make(x1->C + x2->C, x1->H, x1->W);
+            Tensor *l1 = linear_copy(x1), *l2 = linear_copy(x2);
             if (!rc && !net->dry) {
                 const long total = (long)net->B * cat->C * x1->H * x1->W;
                 int g = cdiv(total, 1024); if (g > 4096) g = 4096;
-                hipLaunchKernelGGL(concat_kernel, dim3(g), dim3(256), 0, net->st, ptr(x1), ptr(x2), wptr(cat), x1->C, x2->C, (long)x1->H * x1->W, total);
+                hipLaunchKernelGGL(concat_kernel, dim3(g), dim3(256), 0, net->st, ptr(l1 ? l1 : x1), ptr(l2 ? l2 : x2), wptr(cat), x1->C, x2->C, (long)x1->H * x1->W, total);
             }
+            if (l1) release(l1);
+            if (l2) release(l2);
             if (x1->nst == 1 && x2->nst == 1) { cat->nst = 2; cat->st[0] = x1->st[0]; cat->st[1] = x2->st[0]; }   // rows stay owned by x1 / x2
             x1 = cat;
             x2 = nullptr;
@@ -1003,6 +1041,92 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
 
 // x -> convA (+bias, +residual) -> GroupNorm(+SiLU) from convA's FUSED per-tile statistics -> convB 3x3: the
 // statistics hand-over between a producing convolution and the GroupNorm that follows it, as the executor wires it.
+// Test entry: Upsample (nearest 2x + 3x3 conv, in its parity form when eligible) -> GroupNorm(+SiLU) over cat(mid, skip)
+// -> conv B reading mid as stored (parity-planar after an up2 convolution).  d_mid receives mid as NCHW for checking.
+extern "C" int ipdm_op_up_conv_chain(const float *d_x, int32_t C, int32_t B, int32_t Hs, int32_t Ws, const float *wA_host,
+                                     const float *bA_host, int32_t CA, const float *d_skip, int32_t C2, int32_t groups,
+                                     const float *gamma_host, const float *beta_host, int32_t act, const float *wB_host,
+                                     const float *bB_host, int32_t CB, int32_t ksB, float *d_mid, float *d_out,
+                                     int32_t *used_up2, void *stream)
+{
+    IPDM_REQUIRE(d_x && wA_host && wB_host && gamma_host && beta_host && d_mid && d_out && groups > 0 && (C2 == 0 || d_skip),
+                 "op_up_conv_chain: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int H = 2 * Hs, W = 2 * Ws, Cc = CA + C2;
+    std::vector<float> pA, pU, pB;
+    int cinp, coutpA, coutpB;
+    const int ilA = conv_weight_interleave(CA, 3, 1), ilB = conv_weight_interleave(CB, ksB, 1);
+    conv_pack_weights(wA_host, CA, C, 3, ilA, pA, cinp, coutpA);
+    if (ilA == 2 || ilA == 4) conv_pack_weights_up2(wA_host, CA, C, ilA, pU);
+    conv_pack_weights(wB_host, CB, Cc, ksB, ilB, pB, cinp, coutpB);
+    std::vector<void *> tofree;
+    auto dev = [&](const void *h, size_t bytes, void **out) -> int {
+        void *d = nullptr;
+        IPDM_HIP_CHECK(hipMalloc(&d, bytes ? bytes : 4));
+        if (h) IPDM_HIP_CHECK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+        tofree.push_back(d);
+        *out = d;
+        return IPDM_OK;
+    };
+    float *d_wA, *d_wU = nullptr, *d_wB, *d_bA = nullptr, *d_bB = nullptr, *d_g, *d_be, *d_sc, *d_sh, *d_stats = nullptr, *d_pl = nullptr, *d_lin = nullptr;
+    double *d_part;
+    int rc = dev(pA.data(), pA.size() * 4, (void **)&d_wA);
+    if (!rc && !pU.empty()) rc = dev(pU.data(), pU.size() * 4, (void **)&d_wU);
+    if (!rc) rc = dev(pB.data(), pB.size() * 4, (void **)&d_wB);
+    if (!rc && bA_host) rc = dev(bA_host, CA * 4, (void **)&d_bA);
+    if (!rc && bB_host) rc = dev(bB_host, CB * 4, (void **)&d_bB);
+    if (!rc) rc = dev(gamma_host, Cc * 4, (void **)&d_g);
+    if (!rc) rc = dev(beta_host, Cc * 4, (void **)&d_be);
+    if (!rc) rc = dev(nullptr, ((size_t)B * Cc + 64) * 4, (void **)&d_sc);
+    if (!rc) rc = dev(nullptr, ((size_t)B * Cc + 64) * 4, (void **)&d_sh);
+    if (!rc) rc = dev(nullptr, gn_partials_bytes(B, groups), (void **)&d_part);
+    if (!rc) rc = dev(nullptr, (size_t)B * CA * H * W * 4, (void **)&d_pl);
+    ConvArgs a;
+    a.x1 = d_x; a.x2 = nullptr; a.C1 = C; a.C2 = 0; a.B = B; a.Hs = Hs; a.Ws = Ws; a.H = H; a.W = W; a.upsample = 1;
+    a.scale_y = (float)Hs / (float)H; a.scale_x = (float)Ws / (float)W; a.w = d_wA; a.w_up2 = d_wU; a.cout_pad = coutpA; a.w_interleave = ilA;
+    a.bias = d_bA; a.Cout = CA; a.ksize = 3; a.stride = 1; a.Ho = H; a.Wo = W; a.act = 0; a.gn_scale = a.gn_shift = nullptr; a.res = nullptr;
+    a.out = d_pl; a.tiles_x = a.tiles_y = a.co_tiles = 0;
+    const bool up2 = conv_up2_eligible(a);
+    if (used_up2) *used_up2 = up2 ? 1 : 0;
+    const int rows = C2 == 0 ? conv_stats_rows(a) : 0;      // fused statistics when the GroupNorm covers mid alone
+    if (!rc && rows > 0) {
+        rc = dev(nullptr, (size_t)B * rows * CA * 2 * 4, (void **)&d_stats);
+        if (!rc) IPDM_HIP_CHECK(hipMemsetAsync(d_stats, 0xff, (size_t)B * rows * CA * 2 * 4, st));     // NaN: unwritten rows show
+        a.stats = d_stats; a.stats_rows = rows;
+    }
+    if (!rc) rc = conv2d_launch(a, st);
+    if (!rc && up2) rc = planar_to_linear_launch(d_pl, d_mid, (long)B * CA, H, W, st);
+    else if (!rc) IPDM_HIP_CHECK(hipMemcpyAsync(d_mid, d_pl, (size_t)B * CA * H * W * 4, hipMemcpyDeviceToDevice, st));
+    if (!rc && rows > 0) {
+        GnTileArgs g;
+        g.nsrc = 1; g.src[0].stats = d_stats; g.src[0].rows = rows; g.src[0].C = CA; g.B = B; g.HW = (long)H * W; g.groups = groups;
+        g.gamma = d_g; g.beta = d_be; g.eps = 1e-5f; g.partials = d_part; g.scale = d_sc; g.shift = d_sh;
+        rc = gn_tiles_launch(g, st);
+    } else if (!rc) {
+        GnArgs g;       // (sums over a plane: the parity-planar order of mid does not matter)
+        g.x1 = d_pl; g.x2 = d_skip; g.C1 = CA; g.C2 = C2; g.B = B; g.HW = (long)H * W; g.groups = groups; g.gamma = d_g; g.beta = d_be;
+        g.eps = 1e-5f; g.partials = d_part; g.scale = d_sc; g.shift = d_sh;
+        rc = gn_stats_launch(g, st);
+    }
+    if (!rc) {
+        ConvArgs b;
+        b.x1 = d_pl; b.x2 = d_skip; b.C1 = CA; b.C2 = C2; b.B = B; b.Hs = H; b.Ws = W; b.H = H; b.W = W; b.upsample = 0;
+        b.scale_y = b.scale_x = 1.f; b.w = d_wB; b.cout_pad = coutpB; b.w_interleave = ilB; b.bias = d_bB; b.Cout = CB; b.ksize = ksB;
+        b.stride = 1; b.Ho = H; b.Wo = W; b.act = act; b.gn_scale = d_sc; b.gn_shift = d_sh; b.res = nullptr; b.out = d_out;
+        b.tiles_x = b.tiles_y = b.co_tiles = 0;
+        if (up2 && !conv_planar_ok(b)) {      // a reader that takes NCHW only: convert, as the executor does
+            rc = dev(nullptr, (size_t)B * CA * H * W * 4, (void **)&d_lin);
+            if (!rc) rc = planar_to_linear_launch(d_pl, d_lin, (long)B * CA, H, W, st);
+            b.x1 = d_lin;
+        } else b.x1_planar = up2 ? 1 : 0;
+        if (!rc && conv_split_ws_bytes(b)) { float *d_sp; rc = dev(nullptr, conv_split_ws_bytes(b), (void **)&d_sp); if (!rc) b.split_ws = d_sp; }
+        if (!rc) rc = conv2d_launch(b, st);
+    }
+    (void)hipStreamSynchronize(st);
+    for (void *d : tofree) (void)hipFree(d);
+    return rc;
+}
+
 extern "C" int ipdm_op_conv_gn_conv(const float *d_x, int32_t C, int32_t B, int32_t H, int32_t W, const float *wA_host,
                                     const float *bA_host, int32_t CA, int32_t ksA, int32_t strideA, const float *d_resA,
                                     int32_t groups, const float *gamma_host, const float *beta_host, int32_t act,

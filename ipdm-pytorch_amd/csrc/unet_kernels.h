@@ -35,6 +35,14 @@ struct ConvArgs {
     // ksplit is set by the launcher; callers only provide split_ws (null: never split).
     float *split_ws = nullptr;
     int ksplit = 1;
+    // The convolution of a 2x nearest up-sampled image (Upsample: F.interpolate + 3x3 conv) as four 2x2-tap convolutions on
+    // the source grid, one per output parity, over weights whose coinciding taps were added up at pack time
+    // (conv_pack_weights_up2): 4 instead of 9 multiply-adds per output.  The caller passes the ordinary arguments plus
+    // w_up2; when conv_up2_eligible(args) the launcher takes this path and writes `out` PARITY-PLANAR:
+    // [n][cout][row & 1][col & 1][Ho/2][Wo/2] (same channel stride as NCHW).  Readers set x1_planar (conv_planar_ok).
+    const float *w_up2 = nullptr;
+    int x1_planar = 0;                  // x1 is stored parity-planar (the output of an up2 convolution)
+    int up2 = 0;                        // set by the launcher
     int dbg = 0;                        // IPDM_CONV_DBG bit mask (kernel experiments only; 0 on the product path)
     unsigned long long *dbg_buf = nullptr;   // dbg & 8: per-workgroup cycle stamps [grid][4]
 };
@@ -94,6 +102,13 @@ int conv_split(const ConvArgs &a);                 // K slices the launcher woul
 size_t conv_split_ws_bytes(const ConvArgs &a);     // 0 when conv_split(a) == 1
 constexpr int SPLIT_PIX = 2048;                    // pixels per workgroup (= per statistics row) of the combine pass
 int conv_ws_stats_rows(const ConvArgs &a);
+bool conv_up2_eligible(const ConvArgs &a);         // shape fields + w_up2 + w_interleave decide (dry runs included)
+bool conv_ws_planar_ok(const ConvArgs &a);
+bool conv_planar_ok(const ConvArgs &a);            // the kernel this convolution runs on can read x1 parity-planar
+// [4 parities][Cin_pad][2x2][cout_pad], each parity packed like a ks = 2 convolution of the same interleave
+void conv_pack_weights_up2(const float *w, int Cout, int Cin, int interleave, std::vector<float> &packed);
+// parity-planar [B*C][2][2][H/2][W/2] -> NCHW [B*C][H][W]
+int planar_to_linear_launch(const float *src, float *dst, long planes, int H, int W, hipStream_t st);
 int conv_ws_split(const ConvArgs &a);
 int conv_direct_stats_rows(const ConvArgs &a);
 size_t gn_partials_bytes(int B, int groups);

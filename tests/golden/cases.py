@@ -11,8 +11,12 @@ SMALL_CFGS = {
               channel_mult=(0.25, 0.5, 0.75, 4 / 3), num_heads=1),
     "c": dict(in_channels=1, model_channels=8, out_channels=1, num_res_blocks=1, attention_resolutions=(1, 2),
               channel_mult=(1, 2, 4), num_heads=4),
+    # wide levels at a small size (32 / 64 / 128 channels at 16x24, 8x12, 4x6): both Upsample convolutions double their
+    # input exactly and run on the MFMA kernels, i.e. in the parity form with parity-planar outputs
+    "d": dict(in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=(4,),
+              channel_mult=(1, 2, 4), num_heads=2),
 }
-SMALL_SHAPES = {"a": (2, 1, 24, 20), "b": (1, 1, 23, 19), "c": (1, 1, 12, 10)}
+SMALL_SHAPES = {"a": (2, 1, 24, 20), "b": (1, 1, 23, 19), "c": (1, 1, 12, 10), "d": (2, 1, 16, 24)}
 
 LOOP_CFG = dict(in_channels=1, model_channels=16, out_channels=1, num_res_blocks=1, attention_resolutions=(4,),
                 channel_mult=(1, 1, 2, 4), num_heads=1)

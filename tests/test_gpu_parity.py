@@ -519,6 +519,58 @@ def test_fused_groupnorm_statistics_chain(case):
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
 
 
+@pytest.mark.parametrize("case", [
+    # B, C, Hs, Ws, CA, C2, CB, ksB, act
+    (2, 128, 16, 32, 128, 0, 128, 3, 2),          # 128-cout tiles; GroupNorm from the parity form's fused statistics
+    (1, 64, 13, 21, 64, 64, 64, 3, 2),            # 64-cout tiles, odd source size (ragged tiles in every parity), concat with a skip
+    (2, 256, 9, 17, 256, 128, 128, 1, 2),         # 1x1 reader (the shortcut of the next block) over cat(mid, skip)
+    (1, 128, 12, 20, 128, 16, 16, 3, 2),          # narrow reader (144 -> 16: the direct kernel) of a parity-planar source
+    (1, 128, 12, 20, 128, 16, 16, 1, 0),          # its 1x1 shortcut
+    (1, 16, 10, 12, 16, 0, 16, 3, 2),             # narrow Upsample: not eligible, plain path end to end
+    (1, 256, 4, 4, 256, 0, 256, 3, 1),            # 256 channels at 8x8: reader with a K split
+])
+def test_upsample_conv_parity_form(case):
+    """Upsample (nearest 2x + 3x3 conv) evaluated as four 2x2-tap convolutions over the source grid (the taps that fall on
+    one source pixel added up when the weights are packed), its parity-planar output, the fused statistics of that output
+    and every kind of reader (3x3 / 1x1 wave-specialised kernels with and without a concatenated skip, the narrow direct
+    kernel, a K-split layer) against torch ops in float32: 2e-5 relative like the other convolution tests."""
+    import ctypes
+    import torch.nn.functional as F
+    from ipdm_pytorch_amd import _lib
+    B, C, Hs, Ws, CA, C2, CB, ksB, act = case
+    seed = 5000 + sum(case)
+    x = torch.from_numpy(synth.hash_normal((B, C, Hs, Ws), seed)) * 1.1 + 0.3
+    wA = torch.from_numpy(synth.hash_normal((CA, C, 3, 3), seed + 1)) / np.sqrt(C * 9)
+    bA = torch.from_numpy(synth.hash_normal((CA,), seed + 2))
+    Cc = CA + C2
+    wB = torch.from_numpy(synth.hash_normal((CB, Cc, ksB, ksB), seed + 3)) / np.sqrt(Cc * ksB * ksB)
+    bB = torch.from_numpy(synth.hash_normal((CB,), seed + 4))
+    gamma = torch.from_numpy(synth.hash_uniform((Cc,), seed + 5)) + 0.5
+    beta = torch.from_numpy(synth.hash_normal((Cc,), seed + 6)) * 0.2
+    skip = torch.from_numpy(synth.hash_normal((B, C2, 2 * Hs, 2 * Ws), seed + 7)) * 0.8 if C2 else None
+    groups = ou.gn_groups(Cc)
+    mid = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wA, bA, padding=1)
+    h = torch.cat([mid, skip], 1) if C2 else mid
+    if act:
+        h = F.group_norm(h, groups, gamma, beta, eps=1e-5)
+    if act == 2:
+        h = F.silu(h)
+    want = F.conv2d(h, wB, bB, padding=ksB // 2)
+    d_mid = torch.full(tuple(mid.shape), float("nan"), device=DEV)
+    d_out = torch.full(tuple(want.shape), float("nan"), device=DEV)
+    xd = x.to(DEV)
+    sd = skip.to(DEV) if C2 else None
+    arrs = [np.ascontiguousarray(t.numpy(), dtype=np.float32) for t in (wA, bA, gamma, beta, wB, bB)]
+    used = ctypes.c_int32(-1)
+    _lib.call("ipdm_op_up_conv_chain", _lib.ptr(xd), C, B, Hs, Ws, _lib.ptr(arrs[0]), _lib.ptr(arrs[1]), CA, _lib.ptr(sd), C2,
+              groups, _lib.ptr(arrs[2]), _lib.ptr(arrs[3]), act, _lib.ptr(arrs[4]), _lib.ptr(arrs[5]), CB, ksB, _lib.ptr(d_mid),
+              _lib.ptr(d_out), ctypes.byref(used), _lib.current_stream())
+    assert used.value == (1 if CA > 32 else 0), used.value
+    assert (d_mid.cpu() - mid).abs().max() <= 2e-5 * max(1.0, mid.abs().max().item())
+    err = (d_out.cpu() - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
+
+
 def test_fused_statistics_equal_activation_pass(monkeypatch):
     """The two ways of forming GroupNorm statistics (fused per-tile partial sums / IPDM_GN_UNFUSED=1: a pass over the
     activations) agree to float32 rounding through a whole small UNet, concat inputs and materialised concats included."""
@@ -531,7 +583,7 @@ def test_fused_statistics_equal_activation_pass(monkeypatch):
     assert (a - b).abs().max() <= 5e-6 and float(a.abs().max()) > 0.1
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "d"])
 def test_unet_orientation_equivalence(tag, golden, monkeypatch):
     """The executor may run a forward on spatially transposed activations (3x3 kernels transposed too) when that pads the
     MFMA tiling less (2000x912 sinograms); both orientations must reproduce the reference's outputs (unet_small.npz) and
@@ -574,7 +626,7 @@ def _native_unet(kw, seed):
     return net, {k: torch.from_numpy(v) for k, v in sd.items()}
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "d"])
 def test_unet_small_golden(tag, golden):
     g = golden("unet_small")
     net, sd = _native_unet(SMALL_CFGS[tag], 11)
