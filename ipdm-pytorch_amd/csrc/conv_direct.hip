@@ -41,17 +41,19 @@ __device__ inline float sum_lanes_row(float x)           // over the 16 lanes of
 }
 #undef IPDM_DPP_F
 
-__device__ inline float silu_d(float v)
+// out-of-range per-lane offsets of a raw buffer read 0 (idle staging slots)
+constexpr int DOOB = 0x7fffffff;
+__device__ inline float dload(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * v);
-    return v * __builtin_amdgcn_rcpf(1.0f + e);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
 // DKC: input channels staged per pass.  4 for CO <= 8 (20 KB of LDS and ~90 VGPRs: 5 workgroups per CU instead of 3;
 // 8->8 @2000x912 0.36 vs 0.45 ms), 8 for CO = 16 (whose 64 accumulators bound the occupancy anyway: 4 was 8 % slower).
 // (the second launch bound keeps the register budget of the main loop -- 5 workgroups per CU for CO = 8, 6 for CO = 4 --
 // when the statistics epilogue is compiled in: this loop lives on occupancy)
-template <int CO, int KS, int DKC>
+// PLANAR: x1 is stored parity-planar (ConvArgs::x1_planar: the output of an up-sampling convolution in its parity form)
+template <int CO, int KS, int DKC, bool PLANAR>
 __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_direct_kernel(ConvArgs a)
 {
     constexpr int DIN_H = DT_H + KS - 1, DIN_W = DT_W + KS - 1, DIN_CH = DIN_H * DIN_P, TAPS = KS * KS, PAD = KS / 2;
@@ -61,6 +63,7 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
     // one per CU, shared by the 4 SIMDs -- was the bound of this loop, not the VALU)
     typedef const __attribute__((address_space(4))) float cfloat;
     cfloat *wk = (cfloat *)(unsigned long long)a.w;
+    cfloat *gsc = (cfloat *)(unsigned long long)a.gn_scale, *gsh = (cfloat *)(unsigned long long)a.gn_shift;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const int n = blockIdx.z;
@@ -76,7 +79,7 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
 
     // staging descriptors: element e of the tile = (row r, col c) for every channel of a chunk
     constexpr int NSP = (DIN_H * DIN_W + 255) / 256;
-    int sp_src[NSP], sp_srcp[NSP], sp_dst[NSP];      // sp_srcp: the same element inside a parity-planar x1 (ConvArgs::x1_planar)
+    int sp_src[NSP], sp_srcp[NSP], sp_dst[NSP];      // sp_srcp: the same element inside a parity-planar x1
     bool sp_ok[NSP];
 #pragma unroll
     for (int j = 0; j < NSP; ++j) {
@@ -89,10 +92,15 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
             sy = min((int)floorf((float)sy * a.scale_y), a.Hs - 1);
             sx = min((int)floorf((float)sx * a.scale_x), a.Ws - 1);
         }
-        sp_src[j] = sy * a.Ws + sx;
-        sp_srcp[j] = a.x1_planar ? (((sy & 1) * 2 + (sx & 1)) * (a.Hs >> 1) + (sy >> 1)) * (a.Ws >> 1) + (sx >> 1) : sp_src[j];
+        // byte offsets inside a channel plane (buffer loads: no 64-bit address arithmetic on the VALU, which bounds this kernel)
+        sp_src[j] = e < DIN_H * DIN_W ? (sy * a.Ws + sx) * 4 : DOOB;
+        sp_srcp[j] = !PLANAR ? sp_src[j]
+                   : (e < DIN_H * DIN_W ? ((((sy & 1) * 2 + (sx & 1)) * (a.Hs >> 1) + (sy >> 1)) * (a.Ws >> 1) + (sx >> 1)) * 4 : DOOB);
         sp_dst[j] = e < DIN_H * DIN_W ? r * DIN_P + c : -1;
     }
+    const int plane_bytes = src_plane * 4;
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.x1 + (size_t)n * a.C1 * src_plane), 0, a.C1 * plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.x2 ? a.x2 + (size_t)n * a.C2 * src_plane : a.x1), 0, a.x2 ? a.C2 * plane_bytes : 0, 0x00020000);
 
     for (int c0 = 0; c0 < Ctot; c0 += DKC) {
         const int kc = min(DKC, Ctot - c0);
@@ -102,27 +110,28 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
 #pragma unroll
         for (int c = 0; c < DKC; ++c) {
             const int cg = min(c0 + c, Ctot - 1);          // channels beyond Cin re-read the last one; they are not consumed
-            if (cg < a.C1) {                               // (uniform)
-                const float *src = a.x1 + ((size_t)n * a.C1 + cg) * src_plane;
+            // (no branch around the loads: all loads of the chunk must issue back to back; the source is picked by scalar
+            //  selects, and only a parity-planar x1 costs a per-load select of the offset)
+            const bool from1 = cg < a.C1;
+            const __amdgpu_buffer_rsrc_t r = from1 ? rsrc1 : rsrc2;
+            const int so = (from1 ? cg : cg - a.C1) * plane_bytes;
 #pragma unroll
-                for (int j = 0; j < NSP; ++j) raw[c][j] = src[sp_srcp[j]];
-            } else {
-                const float *src = a.x2 + ((size_t)n * a.C2 + (cg - a.C1)) * src_plane;
-#pragma unroll
-                for (int j = 0; j < NSP; ++j) raw[c][j] = src[sp_src[j]];
-            }
+            for (int j = 0; j < NSP; ++j) raw[c][j] = dload(r, PLANAR && from1 ? sp_srcp[j] : sp_src[j], so);
         }
 #pragma unroll
         for (int c = 0; c < DKC; ++c) {
             if (c < kc) {
                 float sc = 1.0f, sh = 0.0f;
-                if (a.act) { sc = a.gn_scale[(size_t)n * Ctot + c0 + c]; sh = a.gn_shift[(size_t)n * Ctot + c0 + c]; }
+                // (constant address space: scalar loads.  As vector loads they sit behind the chunk's 40 tile loads in the
+                //  in-order memory counter and every channel's transform waits for all of them)
+                if (a.act) { sc = gsc[(size_t)n * Ctot + c0 + c]; sh = gsh[(size_t)n * Ctot + c0 + c]; }
 #pragma unroll
                 for (int j = 0; j < NSP; ++j) {
                     float v = raw[c][j];
                     if (a.act) {
                         v = v * sc + sh;
-                        if (a.act == 2) v = silu_d(v);
+                        // SiLU (a packed two-element form of this transform measured 1 % slower per forward)
+                        if (a.act == 2) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
                     }
                     if (sp_dst[j] >= 0) in_lds[c * DIN_CH + sp_dst[j]] = sp_ok[j] ? v : 0.0f;
                 }
@@ -220,7 +229,8 @@ int launch_direct(const ConvArgs &a, hipStream_t st)
     dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
     const bool prof = prof_enabled();
     if (prof) prof_before(1, st);
-    hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8)>), grid, dim3(256), 0, st, a);
+    if (a.x1_planar) hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), false>), grid, dim3(256), 0, st, a);
     if (prof) prof_after(1, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
@@ -245,8 +255,8 @@ int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
     IPDM_REQUIRE(!a.stats || a.stats_rows == conv_direct_stats_rows(a), "conv2d: statistics rows %d != %d", a.stats_rows,
                  conv_direct_stats_rows(a));
     IPDM_REQUIRE(!a.x1_planar || (!a.upsample && !(a.Hs & 1) && !(a.Ws & 1)), "conv2d: parity-planar input of odd size %dx%d", a.Hs, a.Ws);
-    IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 31) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 31),
-                 "conv2d: per-sample tensor exceeds 32-bit offsets");
+    IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29),
+                 "conv2d: per-sample tensor exceeds the 2 GiB buffer-addressing range");
     if (a.ksize == 1) {     // the 1x1 shortcuts of the narrow levels: pure streaming
         if (a.Cout <= 4) return launch_direct<4, 1>(a, st);
         if (a.Cout <= 8) return launch_direct<8, 1>(a, st);

@@ -270,28 +270,48 @@ __global__ void __launch_bounds__(512) conv_ws_kernel(ConvArgs a, int ntiles)
                     if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_wait += now - p_t; p_t = now; }
                     __syncthreads();                       // A: consumers have finished chunk s-1
                     if (pstamp) p_t = __builtin_amdgcn_s_memtime();
+                    // The staged values of the chunk as a flat list of pairs, transformed FOUR PAIRS ABREAST, stage by
+                    // stage (multiply-add | scale | exp | +1 | rcp | multiply): one pair at a time is a chain of ten
+                    // dependent instructions, four of them transcendental, and the window is as long as that chain times
+                    // the number of pairs.  Each group goes to LDS as soon as it is done (the stores, not VALU, issue
+                    // beside the next group's math); zero padding is re-imposed AFTER the activation (border tiles only).
+                    auto transform = [&](auto silu_tag) __attribute__((always_inline)) {
+                        constexpr bool SILU = decltype(silu_tag)::value;
+                        constexpr int E = KC * T::SP, NPAIR = (E + 1) / 2, GROUP = 8;
 #pragma unroll
-                    for (int c = 0; c < KC; ++c) {
-                        const float sc = scv[c], sh = shv[c];
+                        for (int p0 = 0; p0 < NPAIR; p0 += GROUP) {
+                            f32x2 z[GROUP], e[GROUP];
 #pragma unroll
-                        for (int j = 0; j + 1 < T::SP; j += 2) {
-                            f32x2 v = {raw[c][j], raw[c][j + 1]};
-                            v = a.act == 2 ? gn_silu2(v, sc, sh) : v * sc + sh;
-                            raw[c][j] = v[0];
-                            raw[c][j + 1] = v[1];
+                            for (int g = 0; g < GROUP; ++g) {
+                                const int e0 = 2 * (p0 + g), e1 = e0 + 1 < E ? e0 + 1 : e0;
+                                if (e0 < E)
+                                    z[g] = f32x2{raw[e0 / T::SP][e0 % T::SP], raw[e1 / T::SP][e1 % T::SP]} *
+                                               f32x2{scv[e0 / T::SP], scv[e1 / T::SP]} + f32x2{shv[e0 / T::SP], shv[e1 / T::SP]};
+                            }
+                            if (SILU) {
+#pragma unroll
+                                for (int g = 0; g < GROUP; ++g) if (2 * (p0 + g) < E) e[g] = z[g] * -1.4426950408889634f;
+#pragma unroll
+                                for (int g = 0; g < GROUP; ++g)
+                                    if (2 * (p0 + g) < E) { e[g][0] = __builtin_amdgcn_exp2f(e[g][0]); e[g][1] = __builtin_amdgcn_exp2f(e[g][1]); }
+#pragma unroll
+                                for (int g = 0; g < GROUP; ++g) if (2 * (p0 + g) < E) e[g] = e[g] + 1.0f;
+#pragma unroll
+                                for (int g = 0; g < GROUP; ++g)
+                                    if (2 * (p0 + g) < E) { e[g][0] = __builtin_amdgcn_rcpf(e[g][0]); e[g][1] = __builtin_amdgcn_rcpf(e[g][1]); }
+#pragma unroll
+                                for (int g = 0; g < GROUP; ++g) if (2 * (p0 + g) < E) z[g] = z[g] * e[g];
+                            }
+#pragma unroll
+                            for (int g = 0; g < GROUP; ++g) {
+                                const int e0 = 2 * (p0 + g), e1 = e0 + 1;
+                                if (e0 < E) dst[(e0 / T::SP) * T::IN_CHP + (e0 % T::SP) * 256] = (!border || in_ok[e0 % T::SP]) ? z[g][0] : 0.0f;
+                                if (e1 < E) dst[(e1 / T::SP) * T::IN_CHP + (e1 % T::SP) * 256] = (!border || in_ok[e1 % T::SP]) ? z[g][1] : 0.0f;
+                            }
                         }
-                        if (T::SP & 1) {
-                            f32x2 v = {raw[c][T::SP - 1], 0.0f};
-                            v = a.act == 2 ? gn_silu2(v, sc, sh) : v * sc + sh;
-                            raw[c][T::SP - 1] = v[0];
-                        }
-                        // each channel goes to LDS as soon as it is transformed: the stores (not VALU) issue beside the
-                        // next channel's math instead of forming a tail of the window; zero padding is re-imposed AFTER
-                        // the activation (border tiles only)
-#pragma unroll
-                        for (int j = 0; j < T::SP; ++j)
-                            dst[c * T::IN_CHP + j * 256] = (!border || in_ok[j]) ? raw[c][j] : 0.0f;
-                    }
+                    };
+                    if (a.act == 2) transform(std::true_type{});
+                    else transform(std::false_type{});
                     if (pstamp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                                   const unsigned long long now = __builtin_amdgcn_s_memtime(); p_math += now - p_t; p_t = now; }
                 } else {
@@ -660,7 +680,8 @@ int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
     const bool prof = prof_enabled();
     if (prof) prof_before(prof_cls, st);
     hipLaunchKernelGGL((conv_ws_kernel<KS, STRIDE, MB, NB, KC, IL, PBW, VEC4, PLANAR>), dim3((unsigned)G), dim3(512), LDS_TOTAL, st, a, (int)ntiles);
-    if (prof) prof_after(prof_cls, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
+    // (up2: the four parity convolutions executed, 16 multiply-adds per source pixel -- not the 36 of the 3x3 form)
+    if (prof) prof_after(prof_cls, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS * (a.up2 ? 4 : 1), st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }
@@ -795,8 +816,8 @@ int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
         ConvArgs k = a;
         k.up2 = 1; k.w = a.w_up2; k.ksize = 2; k.upsample = 0; k.H = k.Ho = a.Hs; k.W = k.Wo = a.Ws; k.split_ws = nullptr; k.ksplit = 1;
         // (16-channel chunks -- 16k instead of 8k cycles of MFMA per hand-over -- measured 0.7 % slower per forward)
-        if (a.w_interleave == 4) return launch_ws<2, 1, 4, 2, 8>(k, st, 0);
-        return launch_ws<2, 1, 2, 4, 8>(k, st, 0);
+        if (a.w_interleave == 4) return launch_ws<2, 1, 4, 2, 8>(k, st, 1);
+        return launch_ws<2, 1, 2, 4, 8>(k, st, 1);
     }
     const int S = a.split_ws ? conv_ws_split(a) : 1;
     if (S == 1) return conv2d_ws_dispatch(a, st);
