@@ -313,6 +313,8 @@ def _conv_case(B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res, seed):
     (2, 128, 0, 21, 63, 21, 63, 128, 3, 1, 0, False),       # width % 4 == 3, 63 columns = one full + one ragged tile column
     (2, 256, 0, 17, 57, 17, 57, 256, 1, 1, 0, True),        # 1x1 with residual, width % 4 == 1
     (2, 64, 0, 37, 117, 19, 59, 128, 3, 2, 0, False),       # stride 2 to 19x59
+    (4, 128, 0, 200, 96, 200, 96, 128, 3, 1, 2, True),      # 300 tiles of 8x32x128: one full round of the persistent schedule + a 44-tile tail
+    (2, 128, 64, 203, 90, 203, 90, 256, 3, 1, 2, False),    # two rounds with ragged rows (203), ragged width (90), concat, two cout tiles
 ])
 def test_conv_kernel(case):
     _conv_case(*case, seed=200 + sum(case[:8]))
@@ -468,6 +470,7 @@ def test_reference_blocks_golden(golden):
     (2, 64, 33, 47, 64, 3, 2, False, 2, 64),      # stride-2 producer (Downsample)
     (2, 256, 12, 20, 256, 1, 1, True, 2, 64),     # 1x1 producer with residual (attention proj)
     (8, 256, 32, 32, 256, 3, 1, True, 2, 64),     # the small-tile variant (4x32x64)
+    (4, 128, 200, 96, 128, 3, 1, True, 2, 64),    # several rounds of tiles: statistics rows of a multi-round schedule
     (1, 256, 32, 32, 256, 3, 1, True, 2, 64),     # batch 1: K split, statistics from the combine pass
     (1, 256, 24, 40, 256, 1, 1, True, 2, 64),     # 1x1 producer, K split
     (2, 128, 26, 250, 128, 3, 1, True, 2, 64),    # width % 4 == 2 through the 16-byte epilogue: partial runs in the statistics
