@@ -29,6 +29,7 @@ using namespace ipdm;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -38,6 +39,24 @@ constexpr int VP = 68;         // V pitch  [c][s]
 constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ inline int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Maximum / sum over the two halves of the wave (lanes l and l ^ 32) by v_permlane32_swap (gfx950): one VALU instruction
+// turns two copies of x into {lo, lo} and {hi, hi}.  As __shfl_xor(x, 32) the exchange is a ds_bpermute, an LDS round trip
+// of ~100 cycles that the softmax waits for once per key block (the row maximum feeds every exponential).  Inline
+// assembly: the builtin mis-pairs its two results when both inputs are the same value; the two wait states are the
+// VALU-write -> permlane-read hazard the compiler would insert itself.
+__device__ inline float halves_max(float x)
+{
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+__device__ inline float halves_sum(float x)
+{
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
 
 template <int D, int QT>   // D: head dim C/heads (64 in both reference configs, 32 for reduced test nets); QT: 32-query tiles per wave
 __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restrict__ qkv, float *__restrict__ out,
@@ -120,7 +139,7 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
                 float mx = sacc[qt][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[qt][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = halves_max(mx);
                 const float m_new = fmaxf(m_run[qt], mx);
                 const float mb = -m_new * LOG2E;
                 // exactly 1 while the running max stands (an fma against the rounded mb would leave a 1e-6 residual that
@@ -132,7 +151,7 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
                     sacc[qt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[qt][r], LOG2E, mb));     // exp(s - m_new)
                     rs += sacc[qt][r];
                 }
-                rs += __shfl_xor(rs, 32, 64);
+                rs = halves_sum(rs);
                 l_run[qt] = l_run[qt] * alpha + rs;
                 m_run[qt] = m_new;
                 // the running max settles after the first few key blocks: skip the 32 multiplies by exactly 1.0 (wave-uniform)
@@ -297,17 +316,22 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
                 float mx = sacc[qt][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[qt][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = halves_max(mx);
                 const float m_new = fmaxf(m_run[qt], mx);
                 const float mb = -m_new * LOG2E;
                 const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * LOG2E);
-                float rs = 0.0f;
+                // exp(s - m_new), two scores per packed multiply-add / add (the softmax is VALU beside the MFMA stream)
+                f32x2 rs2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sacc[qt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[qt][r], LOG2E, mb));
-                    rs += sacc[qt][r];
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 v = f32x2{sacc[qt][r], sacc[qt][r + 1]} * LOG2E + mb;
+                    v[0] = __builtin_amdgcn_exp2f(v[0]);
+                    v[1] = __builtin_amdgcn_exp2f(v[1]);
+                    sacc[qt][r] = v[0];
+                    sacc[qt][r + 1] = v[1];
+                    rs2 += v;
                 }
-                rs += __shfl_xor(rs, 32, 64);
+                float rs = halves_sum(rs2[0] + rs2[1]);
                 l_run[qt] = l_run[qt] * alpha + rs;
                 m_run[qt] = m_new;
                 if (__any(alpha != 1.0f)) {
