@@ -8,6 +8,7 @@
 using namespace ipdm;
 
 namespace {
+constexpr long GN_ONE_LAUNCH_MAX = 32768;      // float2 partial sums per group and sample a single block may fold
 
 __device__ __forceinline__ void acc4(const float4 v, double &sum, double &sq)
 {
@@ -152,6 +153,58 @@ __global__ void __launch_bounds__(256) gn_tile_reduce_kernel(GnTileArgs a, int s
     }
 }
 
+// One launch for the common sizes: block (group, sample) folds ALL rows of its group's channels (a thread walks rows
+// tid / cpg', tid / cpg' + 256 / cpg', ... of channel tid % cpg' in float64: a fixed order), the block adds the 256 partial
+// sums in a fixed tree and writes the affine scale / shift of its channels itself -- no partials in memory, no second
+// kernel.  (The two-stage form above keeps the tensors with very many rows: one block per group would stream them alone.)
+__global__ void __launch_bounds__(256) gn_group_kernel(GnTileArgs a)
+{
+    const int g = blockIdx.x, n = blockIdx.y;
+    const int C0 = a.src[0].C, Ctot = C0 + (a.nsrc > 1 ? a.src[1].C : 0);
+    const int cpg = Ctot / a.groups;
+    int cp = 1;
+    while (cp < cpg) cp <<= 1;                        // channels of the group, rounded up to a power of two (<= 256)
+    const int cc = threadIdx.x % cp, ro = threadIdx.x / cp, rpi = 256 / cp;
+    double sum = 0.0, sq = 0.0;
+    if (cc < cpg) {
+        const int c = g * cpg + cc;                   // a group may straddle the two sources of a concat
+        const GnTileSrc src = c < C0 ? a.src[0] : a.src[1];
+        const int cl = c < C0 ? c : c - C0;
+        const float2 *p = reinterpret_cast<const float2 *>(src.stats) + (size_t)n * src.rows * src.C + cl;
+        int r = ro;
+        for (; r + 3 * rpi < src.rows; r += 4 * rpi) {            // four independent loads in flight
+            const float2 v0 = p[(size_t)r * src.C], v1 = p[(size_t)(r + rpi) * src.C],
+                         v2 = p[(size_t)(r + 2 * rpi) * src.C], v3 = p[(size_t)(r + 3 * rpi) * src.C];
+            sum += (double)v0.x + (double)v1.x + (double)v2.x + (double)v3.x;
+            sq += (double)v0.y + (double)v1.y + (double)v2.y + (double)v3.y;
+        }
+        for (; r < src.rows; r += rpi) {
+            const float2 v = p[(size_t)r * src.C];
+            sum += (double)v.x;
+            sq += (double)v.y;
+        }
+    }
+    __shared__ double red[2][4];
+    sum = wave_sum(sum);
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sum; red[1][threadIdx.x >> 6] = sq; }
+    __syncthreads();
+    const double s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double cnt = (double)cpg * (double)a.HW;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;               // biased variance (GroupNorm)
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float meanf = (float)mean;
+    for (int k = threadIdx.x; k < cpg; k += 256) {
+        const int c = g * cpg + k;
+        const float sc = rstd * a.gamma[c];
+        a.scale[(size_t)n * Ctot + c] = sc;
+        a.shift[(size_t)n * Ctot + c] = a.beta[c] - meanf * sc;
+    }
+}
+
 }  // namespace
 
 namespace ipdm {
@@ -165,6 +218,13 @@ int gn_tiles_launch(const GnTileArgs &a, hipStream_t st)
                  Ctot, a.groups);
     int rows = a.src[0].rows;
     if (a.nsrc > 1 && a.src[1].rows > rows) rows = a.src[1].rows;
+    static const bool two_stage = getenv("IPDM_GN_TWO_STAGE") != nullptr;      // A/B: always the two-launch form
+    const int cpg = Ctot / a.groups;
+    if (!two_stage && cpg <= 256 && (long)rows * cpg <= GN_ONE_LAUNCH_MAX) {
+        hipLaunchKernelGGL(gn_group_kernel, dim3(a.groups, a.B), dim3(256), 0, st, a);
+        IPDM_LAUNCH_CHECK();
+        return IPDM_OK;
+    }
     int split = (rows + 63) / 64;                 // >= 64 rows per block
     split = split < 1 ? 1 : (split > GN_SPLIT ? GN_SPLIT : split);
     hipLaunchKernelGGL(gn_tile_reduce_kernel, dim3(split, a.B), dim3(256), 0, st, a, split);
