@@ -531,6 +531,7 @@ def test_fused_groupnorm_statistics_chain(case):
     (1, 128, 12, 20, 128, 16, 16, 1, 0),          # its 1x1 shortcut
     (1, 16, 10, 12, 16, 0, 16, 3, 2),             # narrow Upsample: not eligible, plain path end to end
     (1, 256, 4, 4, 256, 0, 256, 3, 1),            # 256 channels at 8x8: reader with a K split
+    (1, 128, 228, 500, 128, 16, 16, 3, 2),        # production size (transposed sinogram level 500x228 -> 1000x456) and its 144 -> 16 reader
 ])
 def test_upsample_conv_parity_form(case):
     """Upsample (nearest 2x + 3x3 conv) evaluated as four 2x2-tap convolutions over the source grid (the taps that fall on
