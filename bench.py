@@ -250,7 +250,12 @@ def main():
                                    "@512x512, t_start_proj=%s t_start_img=%s ultra=%s" % (
                                        n_fwd_proj, n_fwd_img, args.t_start_proj, args.t_start_img, not args.no_ultra),
                        "slices_per_gpu": B, "global_batch": n_global, "parallelism": "slice-sharded x%d" % world,
-                       "weights": "random-init reference architectures (29.1M img / 28.4M proj params)"},
+                       "weights": "random-init reference architectures (29.1M img / 28.4M proj params)",
+                       "work_per_slice": "85.1 TFLOP as the reference evaluates it; 78.0 TFLOP executed here: the Upsample layers "
+                                         "(nearest 2x + 3x3 conv) run as four 2x2-tap parity convolutions over pre-added weights, "
+                                         "4 of the 9 multiply-adds per output (" + ("on" if not os.environ.get("IPDM_CONV_NO_UP2") else "OFF: IPDM_CONV_NO_UP2") +
+                                         "; DESIGN 6e); the value counts slices, roofline.achieved only 3x3 launches whose executed "
+                                         "and algorithmic FLOPs coincide"},
             "roofline": roofline, "kernels": extra,
         }
         line["dtype"] = {"": "f32", "3": "f32 (wide 3x3 convs: 3-piece split-bf16 operands, 6 MFMA terms, f32 accumulate)",

@@ -706,30 +706,7 @@ int launch_ws(const ConvArgs &a, hipStream_t st, int prof_cls)
 
 namespace ipdm {
 
-// tile height of the variant conv2d_ws_launch picks (every variant's tile is 32 pixels wide)
-static int ws_tile_rows(const ConvArgs &a)
-{
-    if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 4) {
-        const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128) * a.B;
-        return tiles < 160 ? 4 : 8;
-    }
-    if (a.w_interleave == 2 && a.stride == 1) return 16;      // MB = 2, NB = 4 (3x3 and 1x1)
-    return 8;
-}
-
 // ---- K split: which layers, how many slices
-static int ws_tile_couts(const ConvArgs &a)
-{
-    if (a.w_interleave == 4) {
-        if (a.ksize == 3 && a.stride == 1) {
-            const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128) * a.B;
-            return tiles < 160 ? 64 : 128;
-        }
-        return 128;
-    }
-    return 64;
-}
-
 // The number of slices depends on the layer alone (never on the batch size): a slice of a batch must stay bit-equal to
 // the same slice sampled alone or in another shard, and a different K split is a different summation order.  So only
 // layers that cannot fill the chip even at 8 slices per GPU are split: at most 16 of the 8x32-pixel x 128-cout tiles per
@@ -838,7 +815,9 @@ static int conv2d_ws_dispatch(const ConvArgs &a, hipStream_t st)
         // layers whose 8x32x128 tiling gives fewer tiles than CUs (32x32 and 63x29 at 256 channels) use 4x32x64 tiles
         // over the same packed weights: 4x the workgroups, each reading its half of the 128-cout interleave group
         const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128) * a.B;
-        if (tiles < 160) return launch_ws<3, 1, 2, 1, 8, 4>(a, st, 0);
+        // (a K-split launch has ksplit times as many schedule entries: at 8 slices per GPU the 32x32 / 63x29 layers fill the
+        //  chip with full-size tiles, 10 % faster than on quarter tiles; the choice does not change any result)
+        if (tiles * (a.ksplit > 1 ? a.ksplit : 1) < 160) return launch_ws<3, 1, 2, 1, 8, 4>(a, st, 0);
         // (8x4-pixel MFMA blocks -- PBW = 8, tile 32 rows x 8 cols -- pad the 228/114-wide layers 8 % less but measured
         // 3-9 % SLOWER: 32-byte row pieces in every load and store, 18 instead of 12 operand reads per channel pair)
         return launch_ws<3, 1, 4, 2, 8>(a, st, 0);
