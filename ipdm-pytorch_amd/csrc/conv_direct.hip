@@ -48,6 +48,71 @@ __device__ inline float dload(__amdgpu_buffer_rsrc_t r, int voff, int soff)
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
+// ---- epilogue shared by the kernels of this file: + bias (+ residual); 4 consecutive pixels per cout; fused GroupNorm
+// statistics of the output.  ty: the thread's row inside the 64x16 tile; in_lds: the (dead) staging area, >= 2*CO*256 floats
+template <int CO>
+__device__ inline void direct_epilogue(const ConvArgs &a, f32x2 (&acc)[4][CO / 2], int n, int ox0, int oy0, int tx, int ty, float *in_lds)
+{
+    const int tid = threadIdx.x;
+    const int oy = oy0 + ty, ox = ox0 + tx * 4;
+    const bool in_img = oy < a.Ho && ox < a.Wo;
+    const size_t out_plane = (size_t)a.Ho * a.Wo;
+    const bool vec = (a.Wo & 3) == 0;                      // ox is a multiple of 4: whole run inside, 16-byte aligned
+    const bool full_tile = oy0 + DT_H <= a.Ho && ox0 + DT_W <= a.Wo;     // uniform: no pixel of the tile needs masking
+    // Statistics: this loop is VALU-bound, so the 256-way sums go through LDS (its pipe is idle here) instead of DPP
+    // butterflies: every thread parks its 2*CO in-lane sums in LDS ([value][thread], over the input staging area, which
+    // is dead by now), 16 threads per value then add 16 entries each and one DPP row reduction finishes the job.
+    float *st = in_lds;
+    if (a.stats) __syncthreads();                          // every thread is done reading the last chunk's tile
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        if (co < a.Cout) {
+            const float b = a.bias ? a.bias[co] : 0.0f;
+            const size_t o = ((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wo + ox;
+            f32x4 v = {acc[0][co / 2][co & 1] + b, acc[1][co / 2][co & 1] + b, acc[2][co / 2][co & 1] + b, acc[3][co / 2][co & 1] + b};
+            if (in_img) {
+                if (vec) {
+                    if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + o);
+                    *reinterpret_cast<f32x4 *>(a.out + o) = v;
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if (ox + p < a.Wo) {
+                            v[p] += a.res ? a.res[o + p] : 0.0f;
+                            a.out[o + p] = v[p];
+                        }
+                }
+            }
+            if (a.stats) {
+                if (!full_tile) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) v[p] = (in_img && ox + p < a.Wo) ? v[p] : 0.0f;
+                }
+                st[(2 * co) * 256 + tid] = (v[0] + v[1]) + (v[2] + v[3]);
+                st[(2 * co + 1) * 256 + tid] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+            }
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        const int j = tid & 15;                            // 16 threads per value (cout k/2, sum or sum of squares)
+#pragma unroll
+        for (int k = tid >> 4; k < 2 * CO; k += 16) {
+            if ((k >> 1) < a.Cout) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(st + k * 256 + j * 16);
+                const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+                float s = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) +
+                          (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
+                s = sum_lanes_row(s);
+                if (j == 0) {
+                    const int row = blockIdx.y * gridDim.x + blockIdx.x;
+                    a.stats[(((size_t)n * a.stats_rows + row) * a.Cout + (k >> 1)) * 2 + (k & 1)] = s;
+                }
+            }
+        }
+    }
+}
+
 // DKC: input channels staged per pass.  4 for CO <= 8 (20 KB of LDS and ~90 VGPRs: 5 workgroups per CU instead of 3;
 // 8->8 @2000x912 0.36 vs 0.45 ms), 8 for CO = 16 (whose 64 accumulators bound the occupancy anyway: 4 was 8 % slower).
 // (the second launch bound keeps the register budget of the main loop -- 5 workgroups per CU for CO = 8, 6 for CO = 4 --
@@ -162,65 +227,96 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
         }
     }
 
-    // ---- epilogue: + bias (+ residual); 4 consecutive pixels per cout; fused GroupNorm statistics of the output
-    const int oy = oy0 + ty, ox = ox0 + tx * 4;
-    const bool in_img = oy < a.Ho && ox < a.Wo;
-    const size_t out_plane = (size_t)a.Ho * a.Wo;
-    const bool vec = (a.Wo & 3) == 0;                      // ox is a multiple of 4: whole run inside, 16-byte aligned
-    const bool full_tile = oy0 + DT_H <= a.Ho && ox0 + DT_W <= a.Wo;     // uniform: no pixel of the tile needs masking
-    // Statistics: this loop is VALU-bound, so the 256-way sums go through LDS (its pipe is idle here) instead of DPP
-    // butterflies: every thread parks its 2*CO in-lane sums in LDS ([value][thread], over the input staging area, which
-    // is dead by now), 16 threads per value then add 16 entries each and one DPP row reduction finishes the job.
     static_assert(2 * CO * 256 <= DKC * DIN_CH, "conv_direct: statistics staging does not fit the input tile area");
-    float *st = in_lds;
-    if (a.stats) __syncthreads();                          // every thread is done reading the last chunk's tile
+    direct_epilogue<CO>(a, acc, n, ox0, oy0, tx, ty, in_lds);
+}
+
+// The up-sampling convolution (nearest 2x + 3x3, zero padding 1) of a narrow level in its PARITY FORM (conv.hip,
+// conv_pack_weights_up2): output pixel (2y + a, 2x + b) = sum over i, j in {0, 1} of W'[a][b][i][j] . src(y + i + a - 1,
+// x + j + b - 1), 4 multiply-adds per input channel instead of 9, and the staged tile is the 10 x 34 SOURCE window of the
+// 64 x 16 outputs instead of an 18 x 66 window of the up-sampled image.  A thread owns 4 consecutive output pixels
+// (2 source columns x both column parities) of one row; the rows of a wave all have the same parity (waves 0 and 2 take
+// the even rows of their half of the tile, 1 and 3 the odd ones), so the weights stay wave-uniform scalar operands.
+// Output: plain NCHW.  No prologue (the Upsample layer has none).
+template <int CO, int DKC>
+__global__ void __launch_bounds__(256, (CO <= 8 ? 5 : 3)) conv_direct_up2_kernel(ConvArgs a)
+{
+    constexpr int SH = DT_H / 2 + 2, SW = DT_W / 2 + 2, SP = 36, SCH = SH * SP;      // source window, LDS pitch (8-byte aligned runs)
+    constexpr int LDS_FLOATS = (DKC * SCH > 2 * CO * 256) ? DKC * SCH : 2 * CO * 256;   // (the statistics staging reuses it)
+    __shared__ __attribute__((aligned(16))) float in_lds[LDS_FLOATS];
+    typedef const __attribute__((address_space(4))) float cfloat;
+    cfloat *wk = (cfloat *)(unsigned long long)a.w_up2;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tx = lane & 15;
+    const int ty = (wave >> 1) * 8 + (lane >> 4) * 2 + (wave & 1);      // row parity = wave & 1
+    const int par_a = __builtin_amdgcn_readfirstlane(wave & 1);      // (uniform, and the compiler must know: scalar weight loads)
+    const int n = blockIdx.z;
+    const int ox0 = blockIdx.x * DT_W, oy0 = blockIdx.y * DT_H;
+    const int sx0 = (ox0 >> 1) - 1, sy0 = (oy0 >> 1) - 1;              // source coordinates of LDS (0, 0)
+    const int Cin = a.C1, src_plane = a.Hs * a.Ws, plane_bytes = src_plane * 4;
+    const int cin_pad = (Cin + 7) / 8 * 8;                              // rows of one parity's weight slab
+
+    f32x2 acc[4][CO / 2];
 #pragma unroll
-    for (int co = 0; co < CO; ++co) {
-        if (co < a.Cout) {
-            const float b = a.bias ? a.bias[co] : 0.0f;
-            const size_t o = ((size_t)n * a.Cout + co) * out_plane + (size_t)oy * a.Wo + ox;
-            f32x4 v = {acc[0][co / 2][co & 1] + b, acc[1][co / 2][co & 1] + b, acc[2][co / 2][co & 1] + b, acc[3][co / 2][co & 1] + b};
-            if (in_img) {
-                if (vec) {
-                    if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + o);
-                    *reinterpret_cast<f32x4 *>(a.out + o) = v;
-                } else {
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        if (ox + p < a.Wo) {
-                            v[p] += a.res ? a.res[o + p] : 0.0f;
-                            a.out[o + p] = v[p];
-                        }
-                }
-            }
-            if (a.stats) {
-                if (!full_tile) {
+        for (int c = 0; c < CO / 2; ++c) acc[p][c] = f32x2{0.0f, 0.0f};
+
+    constexpr int NSP = (SH * SW + 255) / 256;
+    int sp_src[NSP], sp_dst[NSP];
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) v[p] = (in_img && ox + p < a.Wo) ? v[p] : 0.0f;
-                }
-                st[(2 * co) * 256 + tid] = (v[0] + v[1]) + (v[2] + v[3]);
-                st[(2 * co + 1) * 256 + tid] = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
-            }
-        }
+    for (int j = 0; j < NSP; ++j) {
+        const int e = tid + j * 256;
+        const int r = e / SW, c = e % SW;
+        const int sy = sy0 + r, sx = sx0 + c;
+        const bool ok = e < SH * SW && sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws;      // outside the source: the conv's zero padding
+        sp_src[j] = ok ? (sy * a.Ws + sx) * 4 : DOOB;
+        sp_dst[j] = e < SH * SW ? r * SP + c : -1;
     }
-    if (a.stats) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.x1 + (size_t)n * Cin * src_plane), 0, Cin * plane_bytes, 0x00020000);
+
+    for (int c0 = 0; c0 < Cin; c0 += DKC) {
+        const int kc = min(DKC, Cin - c0);
         __syncthreads();
-        const int j = tid & 15;                            // 16 threads per value (cout k/2, sum or sum of squares)
+        float raw[DKC][NSP];
 #pragma unroll
-        for (int k = tid >> 4; k < 2 * CO; k += 16) {
-            if ((k >> 1) < a.Cout) {
-                const f32x4 *src = reinterpret_cast<const f32x4 *>(st + k * 256 + j * 16);
-                const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
-                float s = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]))) +
-                          (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
-                s = sum_lanes_row(s);
-                if (j == 0) {
-                    const int row = blockIdx.y * gridDim.x + blockIdx.x;
-                    a.stats[(((size_t)n * a.stats_rows + row) * a.Cout + (k >> 1)) * 2 + (k & 1)] = s;
-                }
+        for (int c = 0; c < DKC; ++c) {
+            const int so = min(c0 + c, Cin - 1) * plane_bytes;
+#pragma unroll
+            for (int j = 0; j < NSP; ++j) raw[c][j] = dload(rsrc, sp_src[j], so);
+        }
+#pragma unroll
+        for (int c = 0; c < DKC; ++c)
+#pragma unroll
+            for (int j = 0; j < NSP; ++j)
+                if (sp_dst[j] >= 0) in_lds[c * SCH + sp_dst[j]] = raw[c][j];
+        __syncthreads();
+        for (int c = 0; c < kc; ++c) {
+            // source columns 2 tx .. 2 tx + 3 of the window (x - 1 .. x + 2 for the thread's source pixels x, x + 1)
+            const float *ip = in_lds + c * SCH + ((ty >> 1) + par_a) * SP + tx * 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x2 lo = *reinterpret_cast<const f32x2 *>(ip + i * SP), hi = *reinterpret_cast<const f32x2 *>(ip + i * SP + 2);
+                const float iv[4] = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // [parity a*2+b][Cin_pad8][2x2][cout_pad], plain layout
+                        cfloat *wp = wk + (((size_t)(par_a * 2 + b) * cin_pad + c0 + c) * 4 + i * 2 + j) * a.cout_pad;
+                        f32x2 wv[CO / 2];
+#pragma unroll
+                        for (int q = 0; q < CO / 2; ++q) wv[q] = f32x2{wp[2 * q], wp[2 * q + 1]};
+#pragma unroll
+                        for (int q = 0; q < CO / 2; ++q) {
+                            acc[b][q] += wv[q] * iv[j + b];             // output 2x + b     (source pixel x:     columns 0, 1 | 1, 2)
+                            acc[2 + b][q] += wv[q] * iv[1 + j + b];     // output 2x + 2 + b (source pixel x + 1: columns 1, 2 | 2, 3)
+                        }
+                    }
             }
         }
     }
+    direct_epilogue<CO>(a, acc, n, ox0, oy0, tx, ty, in_lds);
 }
 
 template <int CO, int KS>
@@ -248,6 +344,15 @@ bool conv_direct_eligible(const ConvArgs &a)
            a.cout_pad >= 16;
 }
 
+// the narrow Upsample convolutions in parity form (w_up2 packed with the plain layout): exact 2x, no prologue, one source
+bool conv_direct_up2_eligible(const ConvArgs &a)
+{
+    static const bool off = getenv("IPDM_CONV_NO_UP2") != nullptr;
+    return !off && a.w_up2 && a.w_interleave == 0 && a.ksize == 3 && a.stride == 1 && a.C2 == 0 && a.act == 0 && !a.res &&
+           !a.x1_planar && a.H == 2 * a.Hs && a.W == 2 * a.Ws && a.Ho == a.H && a.Wo == a.W && a.Cout > 4 && a.Cout <= 16 &&
+           a.C1 <= 64 && a.cout_pad >= 16;
+}
+
 int conv_direct_stats_rows(const ConvArgs &a) { return cdiv(a.Wo, DT_W) * cdiv(a.Ho, DT_H); }
 
 int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
@@ -257,6 +362,16 @@ int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
     IPDM_REQUIRE(!a.x1_planar || (!a.upsample && !(a.Hs & 1) && !(a.Ws & 1)), "conv2d: parity-planar input of odd size %dx%d", a.Hs, a.Ws);
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29),
                  "conv2d: per-sample tensor exceeds the 2 GiB buffer-addressing range");
+    if (conv_direct_up2_eligible(a)) {
+        dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
+        const bool prof = prof_enabled();
+        if (prof) prof_before(1, st);
+        if (a.Cout <= 8) hipLaunchKernelGGL((conv_direct_up2_kernel<8, 8>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_direct_up2_kernel<16, 8>), grid, dim3(256), 0, st, a);
+        if (prof) prof_after(1, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * a.C1 * 4, st);      // executed: 4 taps per output
+        IPDM_LAUNCH_CHECK();
+        return IPDM_OK;
+    }
     if (a.ksize == 1) {     // the 1x1 shortcuts of the narrow levels: pure streaming
         if (a.Cout <= 4) return launch_direct<4, 1>(a, st);
         if (a.Cout <= 8) return launch_direct<8, 1>(a, st);

@@ -440,7 +440,7 @@ int make_conv(ipdm_unet *net, const WeightMap &wm, const std::string &wname, con
         conv_pack_weights(wt.data(), cout, cin, ks, out.interleave, packed, cin_pad, cout_pad);
         rc = upload(net, packed.data(), packed.size(), &out.w_t);
         if (rc) return rc;
-        if (up && (out.interleave == 2 || out.interleave == 4)) {      // Upsample: the parity form of both orientations
+        if (up && (out.interleave == 2 || out.interleave == 4 || (out.interleave == 0 && cout <= 16))) {      // Upsample: the parity form of both orientations
             conv_pack_weights_up2(w, cout, cin, out.interleave, packed);
             if ((rc = upload(net, packed.data(), packed.size(), &out.w_up2))) return rc;
             conv_pack_weights_up2(wt.data(), cout, cin, out.interleave, packed);
@@ -664,8 +664,8 @@ struct Fwd {
         if (linr) res = linr;
         a.x1_planar = x1->planar ? 1 : 0;
         struct LinGuard { Fwd &f; Tensor *a, *b, *c; ~LinGuard() { if (a) f.release(a); if (b) f.release(b); if (c) f.release(c); } } lin_guard{*this, lin1, lin2, linr};
-        if (conv_up2_eligible(a) && !ext_out) o->planar = true;
-        else a.w_up2 = nullptr;
+        if (conv_up2_eligible(a) && !ext_out) o->planar = true;                 // wide levels: parity-planar output
+        else if (!conv_direct_up2_eligible(a)) a.w_up2 = nullptr;               // (narrow levels: the direct kernel's parity form writes NCHW)
         // layers with too few tiles to fill the chip are split along K into a scratch buffer (conv_ws.hip)
         const size_t split_bytes = conv_split_ws_bytes(a);
         size_t split_off = (size_t)-1;
@@ -1057,7 +1057,7 @@ extern "C" int ipdm_op_up_conv_chain(const float *d_x, int32_t C, int32_t B, int
     int cinp, coutpA, coutpB;
     const int ilA = conv_weight_interleave(CA, 3, 1), ilB = conv_weight_interleave(CB, ksB, 1);
     conv_pack_weights(wA_host, CA, C, 3, ilA, pA, cinp, coutpA);
-    if (ilA == 2 || ilA == 4) conv_pack_weights_up2(wA_host, CA, C, ilA, pU);
+    if (ilA == 2 || ilA == 4 || (ilA == 0 && CA <= 16)) conv_pack_weights_up2(wA_host, CA, C, ilA, pU);
     conv_pack_weights(wB_host, CB, Cc, ksB, ilB, pB, cinp, coutpB);
     std::vector<void *> tofree;
     auto dev = [&](const void *h, size_t bytes, void **out) -> int {
@@ -1087,7 +1087,7 @@ extern "C" int ipdm_op_up_conv_chain(const float *d_x, int32_t C, int32_t B, int
     a.bias = d_bA; a.Cout = CA; a.ksize = 3; a.stride = 1; a.Ho = H; a.Wo = W; a.act = 0; a.gn_scale = a.gn_shift = nullptr; a.res = nullptr;
     a.out = d_pl; a.tiles_x = a.tiles_y = a.co_tiles = 0;
     const bool up2 = conv_up2_eligible(a);
-    if (used_up2) *used_up2 = up2 ? 1 : 0;
+    if (used_up2) *used_up2 = up2 ? 1 : (conv_direct_up2_eligible(a) ? 2 : 0);      // 2: the direct kernel's parity form (NCHW output)
     const int rows = C2 == 0 ? conv_stats_rows(a) : 0;      // fused statistics when the GroupNorm covers mid alone
     if (!rc && rows > 0) {
         rc = dev(nullptr, (size_t)B * rows * CA * 2 * 4, (void **)&d_stats);

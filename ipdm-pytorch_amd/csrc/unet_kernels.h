@@ -104,6 +104,7 @@ constexpr int SPLIT_PIX = 2048;                    // pixels per workgroup (= pe
 int conv_ws_stats_rows(const ConvArgs &a);
 bool conv_up2_eligible(const ConvArgs &a);         // shape fields + w_up2 + w_interleave decide (dry runs included)
 bool conv_ws_planar_ok(const ConvArgs &a);
+bool conv_direct_up2_eligible(const ConvArgs &a);  // narrow Upsample layers: the same parity form inside conv_direct (NCHW output)
 bool conv_planar_ok(const ConvArgs &a);            // the kernel this convolution runs on can read x1 parity-planar
 // [4 parities][Cin_pad][2x2][cout_pad], each parity packed like a ks = 2 convolution of the same interleave
 void conv_pack_weights_up2(const float *w, int Cout, int Cin, int interleave, std::vector<float> &packed);

@@ -529,13 +529,16 @@ def test_fused_groupnorm_statistics_chain(case):
     (2, 256, 9, 17, 256, 128, 128, 1, 2),         # 1x1 reader (the shortcut of the next block) over cat(mid, skip)
     (1, 128, 12, 20, 128, 16, 16, 3, 2),          # narrow reader (144 -> 16: the direct kernel) of a parity-planar source
     (1, 128, 12, 20, 128, 16, 16, 1, 0),          # its 1x1 shortcut
-    (1, 16, 10, 12, 16, 0, 16, 3, 2),             # narrow Upsample: not eligible, plain path end to end
+    (1, 16, 10, 12, 16, 0, 16, 3, 2),             # narrow Upsample: the direct kernel's parity form (NCHW output)
+    (2, 16, 37, 45, 16, 8, 8, 3, 2),              # the same with ragged tiles on both axes (74x90 outputs) and a concatenated skip
+    (1, 8, 20, 70, 8, 0, 8, 1, 1),                # 8 channels (the CO = 8 instantiation), 1x1 reader
+    (1, 4, 9, 11, 4, 0, 4, 3, 0),                 # 4 channels: not eligible, 3x3 form with nearest addressing
     (1, 256, 4, 4, 256, 0, 256, 3, 1),            # 256 channels at 8x8: reader with a K split
     (1, 128, 228, 500, 128, 16, 16, 3, 2),        # production size (transposed sinogram level 500x228 -> 1000x456) and its 144 -> 16 reader
 ])
 def test_upsample_conv_parity_form(case):
     """Upsample (nearest 2x + 3x3 conv) evaluated as four 2x2-tap convolutions over the source grid (the taps that fall on
-    one source pixel added up when the weights are packed), its parity-planar output, the fused statistics of that output
+    one source pixel added up when the weights are packed; on narrow levels inside the direct kernel), its parity-planar output, the fused statistics of that output
     and every kind of reader (3x3 / 1x1 wave-specialised kernels with and without a concatenated skip, the narrow direct
     kernel, a K-split layer) against torch ops in float32: 2e-5 relative like the other convolution tests."""
     import ctypes
@@ -569,7 +572,7 @@ def test_upsample_conv_parity_form(case):
     _lib.call("ipdm_op_up_conv_chain", _lib.ptr(xd), C, B, Hs, Ws, _lib.ptr(arrs[0]), _lib.ptr(arrs[1]), CA, _lib.ptr(sd), C2,
               groups, _lib.ptr(arrs[2]), _lib.ptr(arrs[3]), act, _lib.ptr(arrs[4]), _lib.ptr(arrs[5]), CB, ksB, _lib.ptr(d_mid),
               _lib.ptr(d_out), ctypes.byref(used), _lib.current_stream())
-    assert used.value == (1 if CA > 32 else 0), used.value
+    assert used.value == (1 if CA > 32 else (2 if CA > 4 else 0)), used.value
     assert (d_mid.cpu() - mid).abs().max() <= 2e-5 * max(1.0, mid.abs().max().item())
     err = (d_out.cpu() - want).abs().max().item()
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
