@@ -28,7 +28,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int DT_W = 64, DT_H = 16;
-constexpr int DIN_P = 68;      // LDS row pitch: 16-byte aligned runs of 4 (+ halo)
+constexpr int DIN_P1 = 68;     // LDS row pitch at stride 1: 16-byte aligned runs of 4 (+ halo); stride 2: 132
 
 // 16-lane sums: DPP row rotations; every lane of the row ends with the total
 #define IPDM_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
@@ -119,10 +119,13 @@ __device__ inline void direct_epilogue(const ConvArgs &a, f32x2 (&acc)[4][CO / 2
 // (the second launch bound keeps the register budget of the main loop -- 5 workgroups per CU for CO = 8, 6 for CO = 4 --
 // when the statistics epilogue is compiled in: this loop lives on occupancy)
 // PLANAR: x1 is stored parity-planar (ConvArgs::x1_planar: the output of an up-sampling convolution in its parity form)
-template <int CO, int KS, int DKC, bool PLANAR>
-__global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_direct_kernel(ConvArgs a)
+// STRIDE 2 (Downsample of the narrow levels, 3x3): the same 64x16 OUTPUT tile over a 33 x 129 input window, 2 channels per pass
+template <int CO, int KS, int DKC, bool PLANAR, int STRIDE = 1>
+__global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3)))) conv_direct_kernel(ConvArgs a)
 {
-    constexpr int DIN_H = DT_H + KS - 1, DIN_W = DT_W + KS - 1, DIN_CH = DIN_H * DIN_P, TAPS = KS * KS, PAD = KS / 2;
+    constexpr int DIN_H = (DT_H - 1) * STRIDE + KS, DIN_W = (DT_W - 1) * STRIDE + KS, DIN_P = STRIDE == 1 ? DIN_P1 : 132;
+    constexpr int DIN_CH = DIN_H * DIN_P, TAPS = KS * KS, PAD = KS / 2;
+    static_assert(STRIDE == 1 || (KS == 3 && !PLANAR), "conv_direct: stride 2 is the 3x3 Downsample");
     __shared__ __attribute__((aligned(16))) float in_lds[DKC * DIN_CH];
     // weights: wave-uniform addresses in the constant address space -> scalar loads; a cout pair is the SGPR operand of
     // one v_pk_fma_f32 (as LDS broadcast reads they cost 9*CO/4 ds_read_b128 per channel and wave, and the LDS pipe --
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
     for (int j = 0; j < NSP; ++j) {
         const int e = tid + j * 256;
         const int r = e / DIN_W, c = e % DIN_W;
-        const int iy = oy0 - PAD + r, ix = ox0 - PAD + c;
+        const int iy = oy0 * STRIDE - PAD + r, ix = ox0 * STRIDE - PAD + c;
         sp_ok[j] = e < DIN_H * DIN_W && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         int sy = min(max(iy, 0), a.H - 1), sx = min(max(ix, 0), a.W - 1);
         if (a.upsample) {   // F.interpolate(mode="nearest"): src = min(floor(dst * (in/out) in f32), in-1)
@@ -216,13 +219,17 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
         else stage(std::integral_constant<int, 0>{});
         __syncthreads();
         for (int c = 0; c < kc; ++c) {
-            const float *ip = in_lds + c * DIN_CH + ty * DIN_P + tx * 4;
+            const float *ip = in_lds + c * DIN_CH + ty * STRIDE * DIN_P + tx * 4 * STRIDE;
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 const f32x4 lo = *reinterpret_cast<const f32x4 *>(ip + ky * DIN_P);
                 f32x2 hi = {0.0f, 0.0f};
-                if (KS > 1) hi = *reinterpret_cast<const f32x2 *>(ip + ky * DIN_P + 4);
-                const float iv[6] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1]};
+                if (KS > 1 && STRIDE == 1) hi = *reinterpret_cast<const f32x2 *>(ip + ky * DIN_P + 4);
+                f32x4 mid = {0.0f, 0.0f, 0.0f, 0.0f};
+                float last = 0.0f;
+                if (STRIDE == 2) { mid = *reinterpret_cast<const f32x4 *>(ip + ky * DIN_P + 4); last = ip[ky * DIN_P + 8]; }
+                // stride 1: the 6 columns x .. x+5 of the 4 outputs' windows; stride 2: the 9 columns 2x .. 2x+8
+                const float iv[9] = {lo[0], lo[1], lo[2], lo[3], STRIDE == 1 ? hi[0] : mid[0], STRIDE == 1 ? hi[1] : mid[1], mid[2], mid[3], last};
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
                     // packed [Cin_pad8][taps][cout_pad] (plain layout), cout_pad >= CO
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(256, (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3))) conv_d
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
 #pragma unroll
-                        for (int q = 0; q < CO / 2; ++q) acc[p][q] += wv[q] * iv[p + kx];
+                        for (int q = 0; q < CO / 2; ++q) acc[p][q] += wv[q] * iv[p * STRIDE + kx];
                 }
             }
         }
@@ -331,6 +338,18 @@ __global__ void __launch_bounds__(256, (CO <= 8 ? 5 : 3)) conv_direct_up2_kernel
     direct_epilogue<CO>(a, acc, n, ox0, oy0, tx, ty, in_lds);
 }
 
+template <int CO>
+int launch_direct_s2(const ConvArgs &a, hipStream_t st)
+{
+    dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
+    const bool prof = prof_enabled();
+    if (prof) prof_before(1, st);
+    hipLaunchKernelGGL((conv_direct_kernel<CO, 3, 2, false, 2>), grid, dim3(256), 0, st, a);
+    if (prof) prof_after(1, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * 9, st);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
 template <int CO, int KS>
 int launch_direct(const ConvArgs &a, hipStream_t st)
 {
@@ -352,6 +371,9 @@ bool conv_direct_eligible(const ConvArgs &a)
 {
     static const int max_cin = getenv("IPDM_DIRECT_MAX_CIN") ? atoi(getenv("IPDM_DIRECT_MAX_CIN")) : 160;
     const int cin = a.C1 + a.C2;
+    static const bool no_s2 = getenv("IPDM_DIRECT_NO_S2") != nullptr;      // A/B: stride 2 on the legacy 4-wave MFMA kernel
+    if (a.stride == 2)
+        return !no_s2 && a.ksize == 3 && a.Cout <= 16 && cin <= 32 && !a.upsample && !a.x1_planar && a.w_interleave == 0 && a.cout_pad >= 16;
     return (a.ksize == 3 || a.ksize == 1) && a.stride == 1 && a.Cout <= 16 && (cin <= max_cin || (a.Cout <= 4 && cin <= 128)) && a.w_interleave == 0 &&
            a.cout_pad >= 16;
 }
@@ -374,6 +396,11 @@ int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
     IPDM_REQUIRE(!a.x1_planar || (!a.upsample && !(a.Hs & 1) && !(a.Ws & 1)), "conv2d: parity-planar input of odd size %dx%d", a.Hs, a.Ws);
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29),
                  "conv2d: per-sample tensor exceeds the 2 GiB buffer-addressing range");
+    if (a.stride == 2) {
+        if (a.Cout <= 4) return launch_direct_s2<4>(a, st);
+        if (a.Cout <= 8) return launch_direct_s2<8>(a, st);
+        return launch_direct_s2<16>(a, st);
+    }
     if (conv_direct_up2_eligible(a)) {
         dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
         const bool prof = prof_enabled();
