@@ -187,36 +187,27 @@ __global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <=
 #pragma unroll
             for (int j = 0; j < NSP; ++j) raw[c][j] = dload(r, PLANAR && from1 ? sp_srcp[j] : sp_src[j], so);
         }
-        // The transform is a third of this kernel's VALU work on the 8-cout layers, so the three prologues are separate
-        // (uniform) code paths without selects, and the exponent's argument is its own multiply-add on the raw value:
-        // z = x sc + sh, t = x (-log2e sc) + (-log2e sh), SiLU = z / (1 + 2^t): 6 instructions per value.
-        // (A packed two-element form measured 1 % slower per forward.)  The zero padding is re-imposed at the store.
-        auto stage = [&](auto act_tag) __attribute__((always_inline)) {
-            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-            for (int c = 0; c < DKC; ++c) {
-                if (c < kc) {
-                    float sc = 1.0f, sh = 0.0f;
-                    // (constant address space: scalar loads.  As vector loads they sit behind the chunk's 40 tile loads in
-                    //  the in-order memory counter and every channel's transform waits for all of them)
-                    if (ACT) { sc = gsc[(size_t)n * Ctot + c0 + c]; sh = gsh[(size_t)n * Ctot + c0 + c]; }
-                    const float sc2 = -1.4426950408889634f * sc, sh2 = -1.4426950408889634f * sh;
+        for (int c = 0; c < DKC; ++c) {
+            if (c < kc) {
+                float sc = 1.0f, sh = 0.0f;
+                // (constant address space: scalar loads.  As vector loads they sit behind the chunk's 40 tile loads in the
+                //  in-order memory counter and every channel's transform waits for all of them)
+                if (a.act) { sc = gsc[(size_t)n * Ctot + c0 + c]; sh = gsh[(size_t)n * Ctot + c0 + c]; }
 #pragma unroll
-                    for (int j = 0; j < NSP; ++j) {
-                        float v = raw[c][j];
-                        if (ACT) {
-                            const float z = fmaf(v, sc, sh);
-                            v = z;
-                            if (ACT == 2) v = z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(raw[c][j], sc2, sh2)));
-                        }
-                        if (sp_dst[j] >= 0) in_lds[c * DIN_CH + sp_dst[j]] = sp_ok[j] ? v : 0.0f;
+                for (int j = 0; j < NSP; ++j) {
+                    float v = raw[c][j];
+                    if (a.act) {
+                        v = v * sc + sh;
+                        // SiLU.  (A packed two-element form of this transform measured 1 % slower per forward; separate code
+                        // paths per prologue with the exponent's argument as its own multiply-add -- 6 instead of 8 VALU
+                        // per value -- gained 1-4 % on most layers but cost the 18-chunk parity-planar reader 65 %.)
+                        if (a.act == 2) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
                     }
+                    if (sp_dst[j] >= 0) in_lds[c * DIN_CH + sp_dst[j]] = sp_ok[j] ? v : 0.0f;
                 }
             }
-        };
-        if (a.act == 2) stage(std::integral_constant<int, 2>{});
-        else if (a.act == 1) stage(std::integral_constant<int, 1>{});
-        else stage(std::integral_constant<int, 0>{});
+        }
         __syncthreads();
         for (int c = 0; c < kc; ++c) {
             const float *ip = in_lds + c * DIN_CH + ty * STRIDE * DIN_P + tx * 4 * STRIDE;
