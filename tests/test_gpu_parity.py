@@ -572,7 +572,8 @@ def test_upsample_conv_parity_form(case):
     _lib.call("ipdm_op_up_conv_chain", _lib.ptr(xd), C, B, Hs, Ws, _lib.ptr(arrs[0]), _lib.ptr(arrs[1]), CA, _lib.ptr(sd), C2,
               groups, _lib.ptr(arrs[2]), _lib.ptr(arrs[3]), act, _lib.ptr(arrs[4]), _lib.ptr(arrs[5]), CB, ksB, _lib.ptr(d_mid),
               _lib.ptr(d_out), ctypes.byref(used), _lib.current_stream())
-    assert used.value == (1 if CA > 32 else (2 if CA > 4 else 0)), used.value
+    wide_mfma = _lib.lib().ipdm_conv_layout_code(CA, 3, 1) in (2, 4)      # (not under the opt-in split-bf16 mode: its 3x3 form stays)
+    assert used.value == (1 if wide_mfma else (2 if 4 < CA <= 16 else 0)), used.value
     assert (d_mid.cpu() - mid).abs().max() <= 2e-5 * max(1.0, mid.abs().max().item())
     err = (d_out.cpu() - want).abs().max().item()
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
