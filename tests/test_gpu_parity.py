@@ -516,7 +516,8 @@ def test_fused_groupnorm_statistics_chain(case):
     _lib.call("ipdm_op_conv_gn_conv", _lib.ptr(xd), C, B, H, W, _lib.ptr(arrs[0]), _lib.ptr(arrs[1]), CA, ksA, sA, _lib.ptr(rd),
               groups, _lib.ptr(arrs[2]), _lib.ptr(arrs[3]), act, _lib.ptr(arrs[4]), _lib.ptr(arrs[5]), CB, _lib.ptr(d_mid),
               _lib.ptr(d_out), ctypes.byref(rows), _lib.current_stream())
-    assert rows.value > 0, rows.value                                  # every kernel family leaves fused statistics
+    split_bf16 = _lib.lib().ipdm_conv_layout_code(CA, ksA, sA) >= 100  # (the opt-in split-bf16 kernels have no fused statistics)
+    assert rows.value > 0 or split_bf16, rows.value                    # every kernel family of the product path leaves fused statistics
     assert (d_mid.cpu() - mid).abs().max() <= 2e-5 * max(1.0, mid.abs().max().item())
     err = (d_out.cpu() - want).abs().max().item()
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
