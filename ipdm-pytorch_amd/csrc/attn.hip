@@ -200,20 +200,39 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const float *__restri
 // registers, MFMAs, softmax), waves 4-7 stage the NEXT K/V tile into the other LDS stage while the consumers work on the
 // current one -- global loads, LDS stores and the barrier latency leave the MFMA waves; one hand-over barrier per tile.
 // The only producer VALU is the 16 multiplies of K by the scale per tile (they fit the MFMA wave's stall gaps).
-template <int D, int QT>
-__global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restrict__ qkv, float *__restrict__ out,
-                                                           int heads, int T, float scale, int zsplit, float *__restrict__ part)
+// Key slices (short sequences, attention_kv_split): every slice is reduced with a FRESH running maximum / sum / output, and
+// the slices are folded in ascending order by this recurrence -- by the workgroup itself when it walks all slices of its
+// queries (zseq), or by attention_combine_kernel when the slices ran as separate workgroups (zsplit).  The same float
+// operations in the same order in both, so how a launch is scheduled (it depends on the batch size) never changes a bit.
+//   M' = max(M, m_k);  a = 2^((M - M') log2e);  b = 2^((m_k - M') log2e);  num = num a + o_k b;  den = den a + l_k b
+struct SliceWeights { float a, b; };
+__device__ inline SliceWeights slice_weights(float &M, float m_k)
+{
+    const float Mn = fmaxf(M, m_k);
+    SliceWeights w;
+    w.a = __builtin_amdgcn_exp2f((M - Mn) * LOG2E);        // first slice: M = -inf -> 0
+    w.b = __builtin_amdgcn_exp2f((m_k - Mn) * LOG2E);
+    M = Mn;
+    return w;
+}
+__device__ inline float slice_fold(float acc, float v, SliceWeights w) { return fmaf(acc, w.a, v * w.b); }
+
+template <int D, int QT, bool ZSEQ = false>      // ZSEQ: a workgroup walks all key slices of its queries (zseq > 1)
+__global__ void __launch_bounds__(512, ZSEQ ? 2 : 1) attention_ws_kernel(const float *__restrict__ qkv, float *__restrict__ out,
+                                                           int heads, int T, float scale, int zsplit, float *__restrict__ part, int zseq)
 {
     // zsplit > 1 (few queries: batch 1, low resolutions): blockIdx.z takes a slice of the key tiles and leaves its
-    // UNNORMALISED output, running maximum and sum in `part`; attention_combine_kernel merges the slices
+    // UNNORMALISED output, running maximum and sum in `part`; attention_combine_kernel merges the slices.
+    // zseq > 1 (the same layer with enough queries to fill the chip): this workgroup walks all zseq slices itself
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STAGE = KV * KP + D * VP;
     const int bh = blockIdx.y;                      // sample*heads + head
     const int b = bh / heads, head = bh % heads;
     const float *qp = qkv + ((size_t)b * heads * 3 * D + (size_t)head * 3 * D) * T;
     const int ntiles = (T + KV - 1) / KV;
-    const int tps = (ntiles + zsplit - 1) / zsplit;
-    const int it0 = blockIdx.z * tps, it1 = min(ntiles, it0 + tps);
+    const int nslice = ZSEQ ? zseq : zsplit;
+    const int tps = (ntiles + nslice - 1) / nslice;                 // key tiles per slice
+    const int it0 = ZSEQ ? 0 : blockIdx.z * tps, it1 = ZSEQ ? ntiles : min(ntiles, it0 + tps);
 
     if (threadIdx.x >= 256) {
         // ------------------------------------------------------------------ producers
@@ -282,6 +301,15 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
     float m_run[QT], l_run[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.0f; }
+    // ZSEQ: the fold of the finished slices (QT = 1 only, like zsplit)
+    static_assert(!ZSEQ || QT == 1, "attention: key slices exist for 32-query waves");
+    f32x16 num[ZSEQ ? CB : 1];
+    float M_all = -INFINITY, den = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < (ZSEQ ? CB : 1); ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) num[cb][r] = 0.0f;
+    int slice_end = it0 + tps;                     // first tile of the next slice
 
     for (int it = it0; it < it1; ++it) {
         const int s0 = it * KV;
@@ -355,6 +383,18 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
                 }
             }
         }
+        if constexpr (ZSEQ) if (it + 1 == slice_end || it + 1 == it1) {
+            // the slice is complete: fold it (ascending order) and start the next one with a fresh state
+            const SliceWeights w = slice_weights(M_all, m_run[0]);
+            den = slice_fold(den, l_run[0], w);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { num[cb][r] = slice_fold(num[cb][r], o[0][cb][r], w); o[0][cb][r] = 0.0f; }
+            m_run[0] = -INFINITY;
+            l_run[0] = 0.0f;
+            slice_end += tps;
+        }
     }
     if (zsplit > 1) {
         float *pp = part + ((size_t)blockIdx.z * gridDim.y + bh) * (D + 2) * T;
@@ -376,46 +416,47 @@ __global__ void __launch_bounds__(512) attention_ws_kernel(const float *__restri
     for (int qt = 0; qt < QT; ++qt) {
         const int t = t0 + qt * 32 + l31;
         if (t < T) {
-            const float inv = 1.0f / l_run[qt];
+            constexpr bool seq = ZSEQ;
+            const float inv = 1.0f / (seq ? den : l_run[qt]);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int c = cb * 32 + crow(r, lh);
-                    op[(size_t)c * T + t] = o[qt][cb][r] * inv;
+                    op[(size_t)c * T + t] = (seq ? num[seq ? cb : 0][r] : o[qt][cb][r]) * inv;
                 }
         }
     }
 }
 
-// merges the key slices of a split launch: out = sum_z w_z o_z / sum_z w_z l_z, w_z = exp(m_z - max m).
+// merges the key slices of a split launch (the recurrence above, ascending slices).
 // Block = (256 queries, sample*head, 16 of the D channels): the weights are recomputed per channel group (2 Z loads) so that
 // four times as many blocks stream the partial outputs.
 template <int D>
-__global__ void __launch_bounds__(256) attention_combine_kernel(const float *__restrict__ part, float *__restrict__ out, int T, int Z)
+__global__ void __launch_bounds__(256) attention_combine_kernel(const float *__restrict__ part, float *__restrict__ out, int T, int Z, int ntiles)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, bh = blockIdx.y, c0 = blockIdx.z * 16;
     if (t >= T) return;
     const size_t slice = (size_t)gridDim.y * (D + 2) * T;
     const float *p = part + (size_t)bh * (D + 2) * T;
-    float m = -INFINITY;
-    for (int z = 0; z < Z; ++z) m = fmaxf(m, p[z * slice + (size_t)D * T + t]);
-    float w[8], L = 0.0f;
+    const int tps = (ntiles + Z - 1) / Z;
+    // the recurrence of slice_weights / slice_fold over the non-empty slices, ascending: exactly what a workgroup that
+    // walks all slices itself (zseq) computes
+    SliceWeights w[8];
+    float M = -INFINITY, den = 0.0f;
 #pragma unroll
-    for (int z = 0; z < 8; ++z) {
-        w[z] = 0.0f;
-        if (z < Z) {
-            w[z] = __builtin_amdgcn_exp2f((p[z * slice + (size_t)D * T + t] - m) * LOG2E);   // an empty slice has m = -inf: weight 0
-            L = fmaf(w[z], p[z * slice + (size_t)(D + 1) * T + t], L);
+    for (int z = 0; z < 8; ++z)
+        if (z < Z && z * tps < ntiles) {
+            w[z] = slice_weights(M, p[z * slice + (size_t)D * T + t]);
+            den = slice_fold(den, p[z * slice + (size_t)(D + 1) * T + t], w[z]);
         }
-    }
-    const float inv = 1.0f / L;
+    const float inv = 1.0f / den;
 #pragma unroll 4
     for (int c = c0; c < c0 + 16; ++c) {
         float acc = 0.0f;
 #pragma unroll
         for (int z = 0; z < 8; ++z)
-            if (z < Z) acc = fmaf(w[z], p[z * slice + (size_t)c * T + t], acc);
+            if (z < Z && z * tps < ntiles) acc = slice_fold(acc, p[z * slice + (size_t)c * T + t], w[z]);
         out[((size_t)bh * D + c) * T + t] = acc * inv;
     }
 }
@@ -468,14 +509,21 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
         constexpr size_t lds = (size_t)2 * (KV * KP + 64 * VP) * sizeof(float);
         if (int rc = ensure_dynamic_lds((const void *)attention_ws_kernel<64, 1>, lds)) return rc;
         if (int rc = ensure_dynamic_lds((const void *)attention_ws_kernel<64, 2>, lds)) return rc;
+        if (int rc = ensure_dynamic_lds((const void *)attention_ws_kernel<64, 1, true>, lds)) return rc;
         const long wg2 = (long)cdiv(T, 256) * B * heads, wg1 = (long)cdiv(T, 128) * B * heads;
         const auto eff = [](long wg) { return (double)wg / (double)(((wg + 255) / 256) * 256); };    // round quantisation
         const int Z = scratch ? attention_kv_split(B, heads, d, T) : 1;
         const bool q2 = Z == 1 && wg2 >= 256 && eff(wg2) >= eff(wg1) - 0.03;     // (the key-slice form exists for 32-query waves)
-        dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads, Z);
-        if (q2) hipLaunchKernelGGL((attention_ws_kernel<64, 2>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, 1, (float *)nullptr);
-        else hipLaunchKernelGGL((attention_ws_kernel<64, 1>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, Z, scratch);
-        if (Z > 1) hipLaunchKernelGGL((attention_combine_kernel<64>), dim3(cdiv(T, 256), B * heads, 4), dim3(256), 0, st, scratch, out, T, Z);
+        // a sliced layer whose query workgroups fill the chip anyway (8 slices per GPU) walks its key slices inside the
+        // workgroup: same arithmetic as the split grid + combine pass, no partial outputs in memory
+        static const bool no_seq = getenv("IPDM_ATTN_NO_ZSEQ") != nullptr;
+        const bool seq = Z >= 4 && !no_seq && wg1 >= 192;     // (2 slices: the split grid + combine pass measured 3 % faster)
+        dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads, seq ? 1 : Z);
+        if (q2) hipLaunchKernelGGL((attention_ws_kernel<64, 2>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, 1, (float *)nullptr, 1);
+        else if (seq) hipLaunchKernelGGL((attention_ws_kernel<64, 1, true>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, 1, (float *)nullptr, Z);
+        else hipLaunchKernelGGL((attention_ws_kernel<64, 1>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, Z, scratch, 1);
+        if (Z > 1 && !seq)
+            hipLaunchKernelGGL((attention_combine_kernel<64>), dim3(cdiv(T, 256), B * heads, 4), dim3(256), 0, st, scratch, out, T, Z, cdiv(T, KV));
     } else if (d == 64) {
         const long wg2 = (long)cdiv(T, 256) * B * heads;
         const bool q2 = wg2 >= 512 && (wg2 % 512 == 0 || wg2 >= 4 * 512);

@@ -356,6 +356,28 @@ def test_attention_kernel(B, heads, T):
     assert (out.cpu() - want).abs().max() <= 2e-5
 
 
+@pytest.mark.parametrize("T", [1024, 1827, 4096, 640])
+def test_attention_key_slices_do_not_depend_on_the_schedule(T):
+    """Short sequences are reduced in key slices whose count depends on the layer alone; a batch that fills the chip walks
+    the slices inside each workgroup, a single slice of the same layer runs them as separate workgroups + a combine pass.
+    Both must give the same bits (sample i of the batch == sample i alone), and match torch."""
+    from ipdm_pytorch_amd import _lib
+    B, heads, d = 8, 4, 64
+    qkv = (torch.from_numpy(synth.hash_normal((B, heads * 3 * d, T), 900 + T)) * 1.3).to(DEV)
+    out = torch.empty((B, heads * d, T), device=DEV)
+    _lib.call("ipdm_op_attention", _lib.ptr(qkv), _lib.ptr(out), B, heads, d, T, _lib.current_stream())
+    for i in (0, 5):
+        one = torch.empty((1, heads * d, T), device=DEV)
+        qi = qkv[i:i + 1].contiguous()
+        _lib.call("ipdm_op_attention", _lib.ptr(qi), _lib.ptr(one), 1, heads, d, T, _lib.current_stream())
+        assert torch.equal(one[0], out[i]), (T, i, float((one[0] - out[i]).abs().max()))
+    q, k, v = qkv[:1].cpu().reshape(heads, 3 * d, T).chunk(3, dim=1)
+    scale = 1.0 / np.sqrt(np.sqrt(d))
+    attn = torch.einsum("bct,bcs->bts", (q * scale).double(), (k * scale).double()).softmax(dim=-1)
+    want = torch.einsum("bts,bcs->bct", attn, v.double()).reshape(1, heads * d, T).float()
+    assert (out[:1].cpu() - want).abs().max() <= 2e-5
+
+
 @pytest.mark.parametrize("B,heads,T", [(1, 4, 117), (2, 4, 1024), (1, 4, 1827), (1, 2, 4096)])
 def test_attention_kernel_split_bf16_x6(B, heads, T, monkeypatch):
     """IPDM_ATTN_SPLIT=3: both contractions as 3-piece split-bf16 (6 MFMA terms, f32 accumulate) at the SAME tolerance
