@@ -99,6 +99,12 @@ def lib():
         if not os.path.isfile(LIB_PATH):
             raise IpdmError("%s not found: the HIP extension is mandatory (no CPU fallback). "
                             "Run __graft_entry__.build()." % LIB_PATH)
+        # torch first: it ships its own libamdhip64, and the library must bind to the SAME runtime instance (loaded the other
+        # way round -- e.g. build() followed by smoke() in one process -- the second runtime sees no device)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)       # AttributeError => header/library mismatch
