@@ -1,20 +1,22 @@
-// Direct 3x3 / 1x1 stride-1 convolution for the narrow layers of the projection-domain UNet (4/8/16 channels at
-// 2000x912 and 1000x456, the stem, the eps output conv): Cout <= 16 and Cin <= 160 (the 144->16 up-block conv included: 71 TF/s on the VALU vs 46 on half-empty MFMA tiles).
+// Direct convolutions for the narrow layers of the projection-domain UNet (4/8/16 channels at 2000x912 and 1000x456, the
+// stem, the eps output conv): 3x3 / 1x1 stride 1, the 3x3 stride-2 Downsample and the Upsample layer in its parity form,
+// Cout <= 16 and Cin <= 160 (the 144->16 up-block conv included).
 //
 // These layers carry 2 % of the FLOPs but took 21 % of a proj forward on the 32-cout MFMA tiles (4-16x padding
 // waste; profiles/r01c layer sweep).  Their arithmetic intensity (Cin*Cout*18 / ((Cin+Cout)*4) = 9-36 FLOP/B) is at
-// or below the HBM ridge, so the right bound is HBM and the right unit is the packed-f32 VALU:
+// or below the HBM ridge, and the packed-f32 VALU has the MFMA's f32 peak, so the unit is v_pk_fma_f32:
 //   * workgroup = 256 threads = a 64 x 16 pixel tile; a thread owns 4 consecutive pixels of one row for ALL couts
 //     (4*CO accumulators), so an input value is read from LDS once per thread and used 9*CO/ (3 overlap) times;
-//   * the haloed input tile [8 ch][18][68] is staged through LDS with the same fused prologue as the MFMA kernels
-//     (nearest up-sampling + concat as addressing, GroupNorm(+SiLU), zero padding after the activation);
-//   * weights of the channel chunk sit in LDS as [ch][tap][CO] and are read as broadcast ds_read_b128 (all lanes
-//     the same address); the inner product is v_pk_fma_f32 over cout pairs with the input value broadcast;
-//   * epilogue: + bias (+ residual), 16-byte stores of the 4 pixels per cout.
-// One pass per tile, 3 workgroups per CU.  Two persistent forms were built and measured slower: producer / consumer wave
-// specialisation (25-35 %), and a loop over (tile, chunk) steps that issues the loads of step s+1 before the FMAs of
-// step s (8->8 @2000x912 0.53 vs 0.45 ms, 16->16 @1000x456 0.43 vs 0.30 ms: the 40 prefetched values cost a wave of
-// occupancy per SIMD, and this VALU-bound loop lives on occupancy).
+//   * the haloed input tile [4 or 8 ch][18][68] is staged through LDS (raw-buffer loads) with the same fused prologue as
+//     the MFMA kernels (nearest up-sampling + concat as addressing, GroupNorm(+SiLU), zero padding after the activation;
+//     a parity-planar x1 through a second offset set, template PLANAR);
+//   * weights are wave-uniform: scalar loads, a cout pair is the SGPR operand of one v_pk_fma_f32 with the input value
+//     broadcast (round 2; as LDS broadcast reads they made the CU's one LDS pipe the bound of the loop);
+//   * epilogue: + bias (+ residual), 16-byte stores of the 4 pixels per cout, fused GroupNorm statistics of the output.
+// One pass per tile, 3-6 workgroups per CU (__launch_bounds__'s second argument is waves per SIMD in HIP).  Two persistent
+// forms were built and measured slower: producer / consumer wave specialisation (25-35 %), and a loop over (tile, chunk)
+// steps that issues the loads of step s+1 before the FMAs of step s (8->8 @2000x912 0.53 vs 0.45 ms, 16->16 @1000x456
+// 0.43 vs 0.30 ms: the 40 prefetched values cost a wave of occupancy per SIMD, and this VALU-bound loop lives on occupancy).
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
