@@ -374,7 +374,7 @@ bool conv_direct_eligible(const ConvArgs &a)
 // the narrow Upsample convolutions in parity form (w_up2 packed with the plain layout): exact 2x, no prologue, one source
 bool conv_direct_up2_eligible(const ConvArgs &a)
 {
-    static const bool off = getenv("IPDM_CONV_NO_UP2") != nullptr;
+    const bool off = getenv("IPDM_CONV_NO_UP2") != nullptr;      // (read per call, like conv_up2_eligible)
     return !off && a.w_up2 && a.w_interleave == 0 && a.ksize == 3 && a.stride == 1 && a.C2 == 0 && a.act == 0 && !a.res &&
            !a.x1_planar && a.H == 2 * a.Hs && a.W == 2 * a.Ws && a.Ho == a.H && a.Wo == a.W && a.Cout > 4 && a.Cout <= 16 &&
            a.C1 <= 64 && a.cout_pad >= 16;

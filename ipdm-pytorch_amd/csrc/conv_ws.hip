@@ -736,7 +736,7 @@ bool conv_ws_planar_ok(const ConvArgs &a)
 // the up-sampling convolution as four parity convolutions (ConvArgs::w_up2): exact 2x nearest, wide layers, no prologue
 bool conv_up2_eligible(const ConvArgs &a)
 {
-    static const bool off = getenv("IPDM_CONV_NO_UP2") != nullptr;
+    const bool off = getenv("IPDM_CONV_NO_UP2") != nullptr;      // (read per call: bench.py times both forms in one process)
     return !off && a.w_up2 && (a.w_interleave == 2 || a.w_interleave == 4) && a.ksize == 3 && a.stride == 1 && a.C2 == 0 &&
            a.act == 0 && !a.res && a.H == 2 * a.Hs && a.W == 2 * a.Ws && a.Ho == a.H && a.Wo == a.W;
 }
