@@ -250,6 +250,7 @@ def main():
                                    "@512x512, t_start_proj=%s t_start_img=%s ultra=%s" % (
                                        n_fwd_proj, n_fwd_img, args.t_start_proj, args.t_start_img, not args.no_ultra),
                        "slices_per_gpu": B, "global_batch": n_global, "parallelism": "slice-sharded x%d" % world,
+                       "rccl_ranks": idist.describe(),
                        "weights": "random-init reference architectures (29.1M img / 28.4M proj params)",
                        "work_per_slice": "85.1 TFLOP as the reference evaluates it; 78.0 TFLOP executed here: the Upsample layers "
                                          "(nearest 2x + 3x3 conv) run as four 2x2-tap parity convolutions over pre-added weights, "

@@ -236,7 +236,8 @@ class progressive_domain_denoiser(EvaluationMixin):
         """Adaptive pass schedule (t_start_proj=None) under slice sharding: the branch is taken on the maximum over
         ALL ranks' slices, as the reference takes it over its whole batch (Model/model.py:596-609)."""
         import torch.distributed as td
-        if not (td.is_available() and td.is_initialized() and td.get_world_size() > 1):
+        if not (td.is_available() and td.is_initialized()
+                and (td.get_world_size() > 1 or getattr(self, "force_collectives", False))):
             return None
         from . import dist as idist
         return lambda v: idist.max_over_ranks(v, self.proj_device)

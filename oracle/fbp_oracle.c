@@ -81,3 +81,49 @@ void ipdm_oracle_backproject(float *I, int BS, const float *pj, const double *ph
         }
     }
 }
+
+/* ---- float64 ARBITER forms (tests only): the same two contractions evaluated in double precision on double data, so that
+ * two float32 evaluations (this oracle's and the HIP library's) can each be measured against the value they both
+ * approximate.  Constants (taps h, nda0) stay the float32 values the reference builds: they define the function. */
+void ipdm_oracle_ramp_f64(const double *pj, const float *h, double *out, int BS, int M, int N)
+{
+    long rows = (long)BS * M;
+#pragma omp parallel for schedule(static)
+    for (long row = 0; row < rows; ++row) {
+        const double *p = pj + row * (long)N;
+        double *o = out + row * (long)N;
+        for (int n = 0; n < N; ++n) {
+            long double acc = 0.0L;
+            for (int j = 0; j < N; ++j)
+                acc += (long double)(p[j] * (double)h[n + N - 1 - j]);
+            o[n] = (double)acc;
+        }
+    }
+}
+
+void ipdm_oracle_backproject_f64(double *I, int BS, const double *pj, const double *phi, const double *r,
+                                 double D, int gridN, int M, int N, const double *theta, double da, float nda0)
+{
+    const double half_pi = 3.141592653589793 / 2;
+    int total = gridN * gridN;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int p = 0; p < total; ++p) {
+        double rr = r[p], ph = phi[p];
+        for (int t = 0; t < M; ++t) {
+            double beta = theta[t] - half_pi;
+            double th = half_pi + beta + ph;
+            double alpha = atan(rr * sin(th) / (D + rr * cos(th)));
+            double u = (alpha - (double)nda0) / da + 0.5;
+            double curdet = floor(u);
+            if (0 < curdet && curdet < N) {
+                double lam = u - curdet;
+                double L = rr * sin(th) / sin(alpha);
+                int c = (int)curdet;
+                for (int k = 0; k < BS; ++k) {
+                    const double *row = pj + ((size_t)k * M + t) * N;
+                    I[(size_t)k * total + p] += ((1 - lam) * row[c - 1] + lam * row[c]) / (L * L);
+                }
+            }
+        }
+    }
+}

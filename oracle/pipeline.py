@@ -23,7 +23,8 @@ def progressive_slice(opt, cfg_p, sd_p, cfg_i, sd_i, ldproj, noise_fn, geo=None,
         constant_guidance=opt["constant_guidance_proj"], noise_fn=noise_fn, kernel_size=opt["kernel_size_proj"],
         amplitude=opt["amplitude_proj"])
     G = 10 if opt["clip_proj"] else 1
-    fbp_img = torch.from_numpy(of.convert(geo, (G * res_p[-1][:, 0]).numpy()))[:, None]
+    fbp = of.convert64 if ldproj.dtype == torch.float64 else of.convert          # float64 input: arbiter run (below)
+    fbp_img = torch.from_numpy(fbp(geo, (G * res_p[-1][:, 0]).numpy()))[:, None]
     x = od.tensor_sharpen(fbp_img, sharpen_num if (opt["convertor"] == "FBP" and opt["fbp_sharpen"]) else -1)
     eps_i = lambda xx, t: ou.unet_forward(cfg_i, sd_i, xx, t)   # noqa: E731
     res_i, _ = od.guided_reverse_process_slice(
@@ -39,15 +40,21 @@ def progressive_slice(opt, cfg_p, sd_p, cfg_i, sd_i, ldproj, noise_fn, geo=None,
     return res_i[-1], dict(proj=res_p, fbp=fbp_img, sharpened=x, img=res_i)
 
 
-def smoke_pipeline_oracle(inputs):
-    """Replays ipdm_pytorch_amd.denoiser.smoke_pipeline on the CPU with the recorded noise."""
+def smoke_pipeline_oracle(inputs, dtype=torch.float32):
+    """Replays ipdm_pytorch_amd.denoiser.smoke_pipeline on the CPU with the recorded noise.
+
+    dtype=torch.float64 is the ARBITER run: the same function -- the same float32 inputs, weights, noise draws, schedule
+    constants and guidance maps -- evaluated in double precision (UNet, statistics, FBP, sharpen), i.e. to ~1e-13 the value
+    that both float32 evaluations (this oracle's and the HIP library's) approximate.  Random-weight networks amplify
+    float32 rounding ~100x end to end, so |HIP - oracle32| alone cannot say which side is off; the distances of each to
+    the arbiter can."""
     from ipdm_pytorch_amd import synth
     opt = inputs["opt"]
     cfg_p = ou.UNetConfig(1, 16, 1, attention_resolutions=(16,), channel_mult=(0.25, 0.25, 0.5, 1, 2, 4), num_heads=1)
     cfg_i = ou.UNetConfig(1, 16, 1, attention_resolutions=(8,), channel_mult=(1, 1, 2, 2, 4), num_heads=1)
-    sd_p = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_p), seed=21).items()}
-    sd_i = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_i), seed=22).items()}
+    sd_p = {k: torch.from_numpy(v).to(dtype) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_p), seed=21).items()}
+    sd_i = {k: torch.from_numpy(v).to(dtype) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_i), seed=22).items()}
     draws = iter(inputs["noise"])
-    out, _ = progressive_slice(opt, cfg_p, sd_p, cfg_i, sd_i, torch.from_numpy(inputs["ldproj"])[None, None],
-                               lambda: next(draws), sharpen_num=70)
+    out, _ = progressive_slice(opt, cfg_p, sd_p, cfg_i, sd_i, torch.from_numpy(inputs["ldproj"])[None, None].to(dtype),
+                               lambda: torch.as_tensor(next(draws)).to(dtype), sharpen_num=70)
     return out.numpy()

@@ -1,0 +1,69 @@
+"""CPU child process of the full-size GPU parity tests: replays ONE slice of the dual-domain sample through the CPU oracle
+(oracle.pipeline.progressive_slice) with the draws the device recorded, and saves the result.  Several of these run side
+by side (one per slice / seed) so that a 75-forward oracle run fits the GPU test budget.  Never touches the GPU.
+
+  python tests/_oracle_child.py job.npz out.npy n_threads
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FULL_IMG = dict(in_channels=1, model_channels=64, out_channels=1, attention_resolutions=(8, 16), channel_mult=(1, 1, 2, 2, 4, 4))
+FULL_PROJ = dict(in_channels=1, model_channels=64, out_channels=1, attention_resolutions=(16, 32),
+                 channel_mult=(1 / 16, 1 / 8, 1 / 4, 2, 2, 4, 4))
+OPT_KEYS = ("timesteps_proj", "schedule_power_proj", "t_start_proj", "clip_proj", "lambda_ratio_proj", "eta_proj",
+            "constant_guidance_proj", "kernel_size_proj", "amplitude_proj", "timesteps_img", "schedule_power_img", "t_start_img",
+            "clip_img", "lambda_ratio_img", "eta_img", "constant_guidance_img", "kernel_size_img", "amplitude_img", "convertor",
+            "fbp_sharpen", "ultra_img_denoise")
+
+
+def write_job(path, opt_dict, sino, draws, weight_seed, sharpen_num):
+    """draws: the recorded [1,1,h,w] tensors/arrays of ONE slice, in order (sinogram-shaped ones first, then image-shaped)."""
+    import numpy as np
+    draws = [np.asarray(d, dtype=np.float32).reshape(d.shape[-2], d.shape[-1]) for d in draws]
+    n_p = sum(1 for d in draws if d.shape == tuple(sino.shape))
+    assert all(d.shape == tuple(sino.shape) for d in draws[:n_p]) and all(d.shape != tuple(sino.shape) for d in draws[n_p:])
+    np.savez(path, sino=np.asarray(sino, dtype=np.float32), draws_p=np.stack(draws[:n_p]), draws_i=np.stack(draws[n_p:]),
+             opt=json.dumps({k: opt_dict[k] for k in OPT_KEYS}), weight_seed=weight_seed, sharpen_num=sharpen_num)
+
+
+def run_jobs(jobs, threads):
+    """jobs: [(job.npz, out.npy)]; runs them as parallel child processes, returns the outputs."""
+    import subprocess
+    import numpy as np
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), j, o, str(threads)], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for j, o in jobs]
+    outs = []
+    for p, (j, o) in zip(procs, jobs):
+        log, _ = p.communicate(timeout=1500)
+        assert p.returncode == 0, log[-3000:]
+        outs.append(np.load(o))
+    return outs
+
+
+def main():
+    job, out, threads = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    import numpy as np
+    import torch
+    torch.set_num_threads(threads)
+    from ipdm_pytorch_amd import synth
+    from oracle import pipeline as op, unet as ou
+    j = np.load(job, allow_pickle=False)
+    opt = json.loads(str(j["opt"]))
+    cfg_p, cfg_i = ou.UNetConfig(**FULL_PROJ), ou.UNetConfig(**FULL_IMG)
+    seed = int(j["weight_seed"])
+    sd_p = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_p), seed=seed).items()}
+    sd_i = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_i), seed=seed).items()}
+    draws = iter([torch.from_numpy(d)[None, None] for d in j["draws_p"]] + [torch.from_numpy(d)[None, None] for d in j["draws_i"]])
+    want, _ = op.progressive_slice(opt, cfg_p, sd_p, cfg_i, sd_i, torch.from_numpy(j["sino"])[None, None],
+                                   lambda: next(draws), sharpen_num=int(j["sharpen_num"]))
+    assert next(draws, None) is None, "the oracle consumed fewer draws than the device recorded"
+    np.save(out, want.numpy())
+
+
+if __name__ == "__main__":
+    main()

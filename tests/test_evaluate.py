@@ -124,6 +124,46 @@ def test_result_writers_and_metric_calculate(tmp_path):
     assert 0 < den.metric_instance["LDCT"]["fsim_iter_0"] <= 1
 
 
+def test_result_figure_save_default_arguments(tmp_path):
+    """The notebook's cell 2 calls result_figure_save(mode="progressive") with its defaults (test_sample.ipynb cell 2;
+    Utils/train_test_utils.py:596): metrics in the reference's order (progressive also scores the converted proj iterates
+    as deProj) and the figure file the reference writes; every mode, never an exception."""
+    den = types.SimpleNamespace(opt=types.SimpleNamespace(metrics=["psnr", "ssim"]))
+    for name in ("metric_clear", "metric_calculate", "metric_update", "save_path_load", "result_figure_save", "_init_evaluation",
+                 "_panel", "_caption"):
+        setattr(den, name, types.MethodType(getattr(ev.EvaluationMixin, name), den))
+    den._pyplot, den._WINDOW = ev.EvaluationMixin._pyplot, ev.EvaluationMixin._WINDOW
+    den.METRIC_MODES = ev.EvaluationMixin.METRIC_MODES
+    den._init_evaluation(str(tmp_path / "figs"))
+    ref, qry = _pair(48, 5, 0.03)
+    mu = (0.183 * (1 + (ref * 4096 - 1024 + 24) / 1000.0)).astype(np.float32)[None, None]
+    den.fdct, den.ldct_np = ref, qry
+    den.fdproj = synth.hash_uniform((20, 12), 3).astype(np.float32)
+    den.ldproj_np = den.fdproj + 0.01
+    stores = {}
+    for name, n in (("progressive_denoise_result", 2), ("proj_denoise_convert2img_result", 3), ("img_denoise_result", 1),
+                    ("proj_denoise_result", 2)):
+        d = ResultTempDict()
+        for i in range(1, n + 1):
+            d["iter_%d" % i] = (den.fdproj[None, None] + 0.001 * i) if name == "proj_denoise_result" else mu + 1e-4 * i
+        setattr(den, name, d)
+        stores[name] = d
+    den.save_path_load(0, "L067", "slice_000")
+    for mode, fname in (("progressive", "progressive.png"), ("dimg", "deImg.png"), ("dproj2img", "deProj2img.png"),
+                        ("dproj", "dProj.png")):
+        den.metric_clear()
+        assert den.result_figure_save(mode=mode, display=False) is None
+        assert os.path.getsize(os.path.join(den.save_path, fname)) > 1000
+    den.metric_clear()
+    assert den.result_figure_save(mode="progressive") is None                       # the notebook's literal call
+    m = den.metric_instance
+    assert list(m["deProj"]) == ["psnr_iter_1", "ssim_iter_1", "psnr_iter_2", "ssim_iter_2", "psnr_iter_3", "ssim_iter_3"]
+    assert list(m["deProg"]) == ["psnr_iter_2", "ssim_iter_2", "psnr_iter_1", "ssim_iter_1"]       # last iterate first
+    assert den.result_figure_save(mode="nonsense") == -1
+    import matplotlib.pyplot as plt
+    plt.close("all")
+
+
 def test_fsim_behaviour():
     ref, q1 = _pair(256, 7, 0.02)
     _, q2 = _pair(256, 7, 0.1)
