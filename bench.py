@@ -87,10 +87,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 leg (N=1 only)")
-    ap.add_argument("--shape", choices=["ref", "alt"], default="ref",
+    ap.add_argument("--shape", choices=["ref", "alt", "img"], default="ref",
                     help="ref: the headline (reference geometry 2000x912, full dual-domain sample).  alt: run the TIMED loop on "
                          "BASELINE config C3's literal shape instead (B x 1152 views x 736 detectors, proj UNet + HIP FBP only) "
-                         "-- for profiling that leg; the default run reports it beside the headline as `alt_shape`")
+                         "-- for profiling that leg; the default run reports it beside the headline as `alt_shape`.  img: BASELINE "
+                         "config C2 (B x 512x512 low-dose images, image-domain UNet only, t_start_img, no ultra pass); reported "
+                         "beside the headline as `img_only`")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the B=1 latency and alt-shape legs (N=1 only)")
     return ap.parse_args()
 
@@ -187,16 +189,29 @@ def main():
     lo, hi = idist.shard_range(n_global, rank, world)
     from ipdm_pytorch_amd.fbp import ALT_GEOMETRY
     den = progressive_domain_denoiser(opt, seed=1234, slice_id0=lo)
-    alt = args.shape == "alt"
+    alt, img_only = args.shape == "alt", args.shape == "img"
     if alt:
         den.set_fbp_geometry(**ALT_GEOMETRY)
     ldproj = make_inputs(B, lo, device, ALT_GEOMETRY if alt else None)
     den.data_sample_load(ldproj=ldproj)
-    n_fwd_proj = sum(args.t_start_proj)
-    n_fwd_img = 0 if alt else sum(args.t_start_img) + (0 if args.no_ultra else 15)
+    n_fwd_proj = 0 if img_only else sum(args.t_start_proj)
+    n_fwd_img = 0 if alt else sum(args.t_start_img) + (0 if (args.no_ultra or img_only) else 15)
+
+    def ldct_images():
+        """C2's input: the low-dose IMAGES (FBP of the low-dose sinograms + the harness's sharpening), resident in HBM."""
+        from ipdm_pytorch_amd.fbp import tensor_sharpen
+        return tensor_sharpen(den._convert_dev(ldproj, 10 if opt.clip_proj else 1), 70).contiguous()
+
+    def img_only_step(x):
+        # img_denoiser(mode="img_only") of the reference (Utils/train_test_utils.py:482-550) without the ultra pass
+        return den._img_dense(x, None, False)[-1]
+    ldct = ldct_images() if img_only else None
 
     def step():
-        out = den.proj_denoiser_device()[0] if alt else den.progressive_denoiser_device(sharpen_num=70)
+        if img_only:
+            out = img_only_step(ldct)
+        else:
+            out = den.proj_denoiser_device()[0] if alt else den.progressive_denoiser_device(sharpen_num=70)
         return idist.all_gather_slices(out, n_global, rank, world)
 
     for _ in range(args.warmup):
@@ -246,6 +261,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE config C3 shape: proj UNet x%d @1152x736 (views x detectors) + HIP FBP to 512x512, "
                                     "t_start_proj=%s (NOT the headline)" % (n_fwd_proj, args.t_start_proj)) if alt else
+                                   ("BASELINE config C2: image-domain only, img UNet x%d @512x512, t_start_img=%s, constant guidance, "
+                                    "no ultra pass (NOT the headline)" % (n_fwd_img, args.t_start_img)) if img_only else
                                    "full dual-domain progressive sample: proj UNet x%d @2000x912 + HIP FBP + img UNet x%d "
                                    "@512x512, t_start_proj=%s t_start_img=%s ultra=%s" % (
                                        n_fwd_proj, n_fwd_img, args.t_start_proj, args.t_start_img, not args.no_ultra),
@@ -262,7 +279,8 @@ def main():
         line["dtype"] = {"": "f32", "3": "f32 (wide 3x3 convs: 3-piece split-bf16 operands, 6 MFMA terms, f32 accumulate)",
                          "2": "f32 (wide 3x3 convs: 2-piece split-bf16 operands, 3 MFMA terms, f32 accumulate)"}.get(
                              os.environ.get("IPDM_CONV_SPLIT", ""), "f32")
-        if world == 1 and not args.no_extra_legs and not alt and not os.environ.get("IPDM_CONV_SPLIT"):
+        ref_shape = not alt and not img_only
+        if world == 1 and not args.no_extra_legs and ref_shape and not os.environ.get("IPDM_CONV_SPLIT"):
             # ---- B = 1 latency (the reference is a one-slice-at-a-time tool): same workload, one slice
             den.data_sample_load(ldproj=ldproj[:1].contiguous())
 
@@ -302,12 +320,21 @@ def main():
                 "value": round(B / dta, 5), "unit": "slices/s", "ms_per_step": round(dta * 1e3, 2), "steps": 1}
             den.set_fbp_geometry()
             den.data_sample_load(ldproj=ldproj)
-        if world == 1 and not args.no_alt and not alt and not os.environ.get("IPDM_CONV_SPLIT"):
+            # ---- BASELINE config C2: B x 512x512 low-dose images, image-domain UNet only, t_start_img, no ultra pass
+            x_img = ldct_images()
+            dti, oi = timed_leg(lambda: img_only_step(x_img))
+            assert tuple(oi.shape) == (B, 1, 512, 512) and bool(torch.isfinite(oi).all())
+            line["img_only"] = {
+                "workload": "B=%d low-dose 512x512 images (HIP FBP of the low-dose sinograms, sharpened), image-domain UNet x%d only, "
+                            "t_start_img=%s, constant guidance %.2f, no ultra pass (BASELINE config C2)" % (
+                                B, sum(args.t_start_img), args.t_start_img, opt.constant_guidance_img),
+                "value": round(B / dti, 5), "unit": "slices/s", "ms_per_step": round(dti * 1e3, 2), "steps": 1}
+        if world == 1 and not args.no_alt and ref_shape and not os.environ.get("IPDM_CONV_SPLIT"):
             # opt-in mode measured beside the headline (never the headline): same workload, same inputs
             del den
             torch.cuda.empty_cache()
-            os.environ["IPDM_CONV_SPLIT"] = "3"
-            os.environ["IPDM_ATTN_SPLIT"] = "3"
+            _lib.set_option("conv_split", 3)
+            _lib.set_option("attn_split", 3)
             try:
                 from ipdm_pytorch_amd.diffusion import NoiseSource
                 den2 = progressive_domain_denoiser(opt, seed=1234, slice_id0=lo)
@@ -335,12 +362,12 @@ def main():
                             "not the headline"}}
                 del den2
             finally:
-                del os.environ["IPDM_CONV_SPLIT"]
-                del os.environ["IPDM_ATTN_SPLIT"]
+                _lib.set_option("conv_split", 0)
+                _lib.set_option("attn_split", 0)
             # the headline's one algebraic shortcut switched off: every Upsample layer as the reference's 3x3 convolution over
             # the nearest-upsampled image (9 instead of 4 multiply-adds per output): all 85.1 TFLOP per slice executed
             torch.cuda.empty_cache()
-            os.environ["IPDM_CONV_NO_UP2"] = "1"
+            _lib.set_option("conv_no_up2", 1)
             try:
                 den3 = progressive_domain_denoiser(opt, seed=1234, slice_id0=lo)
                 den3.data_sample_load(ldproj=ldproj)
@@ -364,7 +391,7 @@ def main():
                             "its one algebraic shortcut; same inputs and noise draws as the headline's last timed step"}
                 del den3
             finally:
-                del os.environ["IPDM_CONV_NO_UP2"]
+                _lib.set_option("conv_no_up2", 0)
         if not args.no_cpu_baseline and world == 1:
             tb, used, cores = cpu_baseline()
             per_slice = n_fwd_proj * tb["proj"] + n_fwd_img * tb["img"] + tb["fbp"]

@@ -34,6 +34,18 @@ const char *ipdm_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
 int ipdm_abi_version(void);
 
+/* Process-wide switches of the library (A/B experiments, opt-in evaluation modes); no reference counterpart -- the
+ * reference's only knobs are its option keys (Config/default_config.py), which stay in the Python layer.
+ * `name` is lower case, e.g. "conv_split" (0 | 2 | 3: split-bf16 evaluation of the wide 3x3 convolutions), "attn_split"
+ * (0 | 3), "conv_no_up2" (Upsample layers in the reference's 3x3 form), "conv_no_wino", "gn_unfused", "unet_transpose"
+ * (-1 | 0 | 1) ...; README.md lists them.  Every switch starts from the environment variable IPDM_<NAME> (read once, kept
+ * as a debug alias) and changes only through this call afterwards.  Switches that shape packed weights or kernel choice
+ * are recorded by ipdm_unet_create: a forward on a handle created under other values fails with IPDM_ERR_INVALID instead
+ * of running on a mismatched layout; per-call switches (conv_no_up2, gn_two_stage, attn_no_zseq, conv_dbg,
+ * art_per_view) may change under a live handle.  Returns IPDM_ERR_INVALID for an unknown name. */
+int ipdm_set_option(const char *name, int value);
+int ipdm_get_option(const char *name, int *value);
+
 /* ------------------------------------------------------------------ FBP domain convertor ---- */
 /* Geometry of Recon/FBP_kernel.py:28-67 (FBP.__init__); the defaults of the reference are
  * n_views=2000 n_det=912 grid_n=512 da=0.0010125 det_offset=3.75 dtheta_deg=0.18

@@ -34,6 +34,8 @@ _vp, _i32, _i64, _u64, _f32, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_u
 PROTOTYPES = {
     "ipdm_last_error": (C.c_char_p, []),
     "ipdm_abi_version": (C.c_int, []),
+    "ipdm_set_option": (C.c_int, [C.c_char_p, _i32]),
+    "ipdm_get_option": (C.c_int, [C.c_char_p, C.POINTER(_i32)]),
     "ipdm_fbp_plan_create": (C.c_int, [C.POINTER(FbpGeom), C.POINTER(_vp)]),
     "ipdm_fbp_plan_destroy": (C.c_int, [_vp]),
     "ipdm_fbp_workspace_bytes": (_sz, [_vp, _i32]),
@@ -120,6 +122,34 @@ def call(name, *args):
     if rc != 0:
         raise IpdmError("%s failed (%d): %s" % (name, rc, lib().ipdm_last_error().decode()))
     return rc
+
+
+def set_option(name, value):
+    """ipdm_set_option: process-wide library switch (README.md lists them); returns the previous value."""
+    old = get_option(name)
+    call("ipdm_set_option", name.encode(), int(value))
+    return old
+
+
+def get_option(name):
+    v = C.c_int32()
+    call("ipdm_get_option", name.encode(), C.byref(v))
+    return v.value
+
+
+class option:
+    """with _lib.option("conv_split", 3): ...  -- sets a library switch for the block and restores it afterwards."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 def ptr(t):

@@ -694,7 +694,7 @@ extern "C" int ipdm_art_plan_create(const ipdm_art_geom *g, const float *lut, co
         IPDM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         IPDM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, art_sweep_persistent_kernel, 256, 0));
         const long tiles = (long)cdiv(g->nx, 16) * cdiv(g->ny, 16);
-        p->persistent_ok = getenv("IPDM_ART_PER_VIEW") == nullptr && tiles <= (long)per_cu * cus &&
+        p->persistent_ok = !ipdm::opt(ipdm::OPT_ART_PER_VIEW) && tiles <= (long)per_cu * cus &&
                            tiles <= (long)SYNC_GROUP * SYNC_MAX_GROUPS;
     }
     *out = p;

@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(256) attention_combine_kernel(const float *__r
 // half of the chip; at 8 slices per GPU the split costs those launches a few per cent for the combine pass).
 int attention_kv_split(int B, int heads, int d, int T)
 {
-    static const bool off = getenv("IPDM_ATTN_NO_KVSPLIT") != nullptr;
+    const bool off = opt(OPT_ATTN_NO_KVSPLIT) != 0;
     (void)B;
     if (off || d != 64) return 1;
     const long wg = (long)cdiv(T, 128) * heads;
@@ -498,9 +498,8 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
     const float scale = (float)(1.0 / sqrt(sqrt((double)d)));
     const bool prof = prof_enabled();
     if (prof) prof_before(2, st);
-    static const bool legacy = getenv("IPDM_ATTN_LEGACY") != nullptr;
-    const char *split_env = getenv("IPDM_ATTN_SPLIT");      // read per launch: one process may run both modes
-    if (d == 64 && split_env && atoi(split_env) == 3) {
+    const bool legacy = opt(OPT_ATTN_LEGACY) != 0;
+    if (d == 64 && opt(OPT_ATTN_SPLIT) == 3) {
         const int rc = attention_sx_launch(qkv, scratch, out, B, heads, T, scale, st);
         if (rc) return rc;
     } else if (d == 64 && !legacy) {
@@ -516,7 +515,7 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
         const bool q2 = Z == 1 && wg2 >= 256 && eff(wg2) >= eff(wg1) - 0.03;     // (the key-slice form exists for 32-query waves)
         // a sliced layer whose query workgroups fill the chip anyway (8 slices per GPU) walks its key slices inside the
         // workgroup: same arithmetic as the split grid + combine pass, no partial outputs in memory
-        static const bool no_seq = getenv("IPDM_ATTN_NO_ZSEQ") != nullptr;
+        const bool no_seq = opt(OPT_ATTN_NO_ZSEQ) != 0;
         const bool seq = Z >= 4 && !no_seq && wg1 >= 192;     // (2 slices: the split grid + combine pass measured 3 % faster)
         dim3 grid(cdiv(T, q2 ? 256 : 128), B * heads, seq ? 1 : Z);
         if (q2) hipLaunchKernelGGL((attention_ws_kernel<64, 2>), grid, dim3(512), lds, st, qkv, out, heads, T, scale, 1, (float *)nullptr, 1);
@@ -543,9 +542,8 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
 
 extern "C" int32_t ipdm_attention_kernel_code(int32_t d)
 {
-    const char *split_env = getenv("IPDM_ATTN_SPLIT");
-    if (d == 64 && split_env && atoi(split_env) == 3) return 3;
-    return (d == 64 && getenv("IPDM_ATTN_LEGACY") == nullptr) ? 1 : 0;
+    if (d == 64 && ipdm::opt(ipdm::OPT_ATTN_SPLIT) == 3) return 3;
+    return (d == 64 && !ipdm::opt(ipdm::OPT_ATTN_LEGACY)) ? 1 : 0;
 }
 
 extern "C" int ipdm_op_attention(const float *d_qkv, float *d_out, int32_t B, int32_t heads, int32_t d, int32_t T,

@@ -34,6 +34,31 @@ void set_error(const char *fmt, ...);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- process-wide switches (ipdm_set_option / ipdm_get_option of the ABI).  One table instead of getenv() calls scattered
+// over the launch paths: every entry is read from the environment ONCE (IPDM_<NAME>, kept as a debug alias), after that
+// only ipdm_set_option changes it.  A UNet handle records the table at ipdm_unet_create; a forward refuses to run when
+// an entry that shapes packed weights, workspace layout or kernel choice differs from that record (OPT_PER_CALL entries
+// excepted), so a switch flipped between create and forward is an error, not a silently mismatched layout.
+enum Opt {
+    OPT_CONV_SPLIT,          // 0 | 2 | 3: opt-in split-bf16 evaluation of the wide 3x3 convolutions (weights packed for it)
+    OPT_ATTN_SPLIT,          // 0 | 3: opt-in split-bf16 attention
+    OPT_CONV_NO_UP2,         // Upsample layers in the reference's 3x3 form (per call: both weight sets are packed)
+    OPT_CONV_LEGACY, OPT_CONV1X1_LEGACY, OPT_CONVS2_LEGACY,      // route kernel families to the round-1 4-wave kernels
+    OPT_CONV_NO_DIRECT, OPT_DIRECT_NO_PLANAR, OPT_DIRECT_MAX_CIN, OPT_DIRECT_NO_S2,
+    OPT_CONV_SX_CW2, OPT_CONV_DBG, OPT_CONV_VEC4_STRICT, OPT_CONV_NO_SPLITK, OPT_CONV_NO_WINO, OPT_CONV_NO_FUSE1X1,
+    OPT_GN_TWO_STAGE, OPT_GN_UNFUSED,
+    OPT_UNET_TRANSPOSE,      // -1 automatic | 0 never | 1 always
+    OPT_ATTN_NO_KVSPLIT, OPT_ATTN_LEGACY, OPT_ATTN_NO_ZSEQ,
+    OPT_ART_PER_VIEW,
+    OPT_COUNT
+};
+int opt(Opt o);
+bool opt_per_call(int o);                 // entries a live handle tolerates being changed
+const char *opt_name(int o);
+void opt_snapshot(int (&dst)[OPT_COUNT]);
+// first entry (not per-call) whose current value differs from `rec`, or -1
+int opt_changed_since(const int (&rec)[OPT_COUNT]);
+
 // hipFuncAttributeMaxDynamicSharedMemorySize for kernels that use more than 64 KiB of LDS: set once per
 // (kernel, device), under a lock -- handles may be driven from different threads and devices of one process.
 int ensure_dynamic_lds(const void *kernel, size_t bytes);

@@ -1,4 +1,7 @@
+#include <cctype>
+#include <cstdlib>
 #include <mutex>
+#include <strings.h>
 #include <set>
 #include <utility>
 #include "common.h"
@@ -18,6 +21,75 @@ std::mutex g_attr_mu;
 std::set<std::pair<const void *, int>> g_attr_done;    // (kernel, device) pairs already configured
 int g_cus[64];                                         // per device ordinal, 0 = not read yet
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------- options
+namespace {
+struct OptDef { const char *name; int def; bool per_call; };
+const OptDef g_opt_def[OPT_COUNT] = {
+    {"conv_split", 0, false}, {"attn_split", 0, false}, {"conv_no_up2", 0, true},
+    {"conv_legacy", 0, false}, {"conv1x1_legacy", 0, false}, {"convs2_legacy", 0, false},
+    {"conv_no_direct", 0, false}, {"direct_no_planar", 0, false}, {"direct_max_cin", 160, false}, {"direct_no_s2", 0, false},
+    {"conv_sx_cw2", 0, false}, {"conv_dbg", 0, true}, {"conv_vec4_strict", 0, false}, {"conv_no_splitk", 0, false},
+    {"conv_no_wino", 0, false}, {"conv_no_fuse1x1", 0, false},
+    {"gn_two_stage", 0, true}, {"gn_unfused", 0, false},
+    {"unet_transpose", -1, false},
+    {"attn_no_kvsplit", 0, false}, {"attn_legacy", 0, false}, {"attn_no_zseq", 0, true},
+    {"art_per_view", 0, true},
+};
+std::mutex g_opt_mu;
+int g_opt_val[OPT_COUNT];
+bool g_opt_init = false;
+
+void opt_init_locked()
+{
+    if (g_opt_init) return;
+    for (int i = 0; i < OPT_COUNT; ++i) {
+        char env[64] = "IPDM_";
+        size_t n = 5;
+        for (const char *c = g_opt_def[i].name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper((unsigned char)*c);
+        env[n] = 0;
+        const char *e = getenv(env);
+        g_opt_val[i] = g_opt_def[i].def;
+        if (e) {                       // presence switches a flag on; a number is taken as the value ("0" switches it off)
+            char *end = nullptr;
+            const long v = strtol(e, &end, 10);
+            g_opt_val[i] = (end != e) ? (int)v : 1;
+        }
+    }
+    g_opt_init = true;
+}
+}  // namespace
+
+int opt(Opt o)
+{
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    opt_init_locked();
+    return g_opt_val[o];
+}
+bool opt_per_call(int o) { return g_opt_def[o].per_call; }
+const char *opt_name(int o) { return g_opt_def[o].name; }
+void opt_snapshot(int (&dst)[OPT_COUNT])
+{
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    opt_init_locked();
+    for (int i = 0; i < OPT_COUNT; ++i) dst[i] = g_opt_val[i];
+}
+int opt_changed_since(const int (&rec)[OPT_COUNT])
+{
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    opt_init_locked();
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!g_opt_def[i].per_call && g_opt_val[i] != rec[i]) return i;
+    return -1;
+}
+static int opt_find(const char *name)
+{
+    if (!name) return -1;
+    if (!strncmp(name, "IPDM_", 5) || !strncmp(name, "ipdm_", 5)) name += 5;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcasecmp(name, g_opt_def[i].name)) return i;
+    return -1;
+}
 
 int ensure_dynamic_lds(const void *kernel, size_t bytes)
 {
@@ -43,3 +115,21 @@ int device_cu_count()
 
 extern "C" const char *ipdm_last_error(void) { return ipdm::g_err; }
 extern "C" int ipdm_abi_version(void) { return 1; }
+
+extern "C" int ipdm_set_option(const char *name, int value)
+{
+    const int i = ipdm::opt_find(name);
+    IPDM_REQUIRE(i >= 0, "ipdm_set_option: unknown option '%s'", name ? name : "(null)");
+    std::lock_guard<std::mutex> lk(ipdm::g_opt_mu);
+    ipdm::opt_init_locked();
+    ipdm::g_opt_val[i] = value;
+    return IPDM_OK;
+}
+
+extern "C" int ipdm_get_option(const char *name, int *value)
+{
+    const int i = ipdm::opt_find(name);
+    IPDM_REQUIRE(i >= 0 && value, "ipdm_get_option: unknown option '%s'", name ? name : "(null)");
+    *value = ipdm::opt((ipdm::Opt)i);
+    return IPDM_OK;
+}

@@ -375,8 +375,7 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
     // when their weights were packed for it (conv_weight_interleave); IPDM_CONV_LEGACY=1 at pack time keeps them here
     if (conv_sx_pieces(a.w_interleave)) return conv2d_sx_launch(a, st);
     if (a.w_interleave) return conv2d_ws_launch(a, st);
-    static const bool no_direct = getenv("IPDM_CONV_NO_DIRECT") != nullptr;
-    if (!no_direct && conv_direct_eligible(a)) return conv2d_direct_launch(a, st);
+    if (!opt(OPT_CONV_NO_DIRECT) && conv_direct_eligible(a)) return conv2d_direct_launch(a, st);
     if (a.ksize == 3 && a.stride == 1) return wide ? launch_conv<3, 1, 2, 2, 8>(a, st) : launch_conv<3, 1, 1, 2, 8>(a, st);
     if (a.ksize == 3 && a.stride == 2) return wide ? launch_conv<3, 2, 2, 1, 8>(a, st) : launch_conv<3, 2, 1, 1, 8>(a, st);
     if (a.ksize == 1 && a.stride == 1) return wide ? launch_conv<1, 1, 2, 2, 8>(a, st) : launch_conv<1, 1, 1, 2, 8>(a, st);
@@ -389,8 +388,7 @@ int conv_stats_rows(const ConvArgs &a)
 {
     if (conv_sx_pieces(a.w_interleave)) return 0;                       // opt-in split-bf16 kernels: no fused statistics
     if (a.w_interleave) return conv_ws_stats_rows(a);
-    static const bool no_direct = getenv("IPDM_CONV_NO_DIRECT") != nullptr;
-    if (!no_direct && conv_direct_eligible(a)) return conv_direct_stats_rows(a);
+    if (!opt(OPT_CONV_NO_DIRECT) && conv_direct_eligible(a)) return conv_direct_stats_rows(a);
     return a.Ho * cdiv(a.Wo, 32);                                       // the 4-wave kernels below: a row per pixel row and tile column
 }
 
@@ -439,9 +437,8 @@ bool conv_planar_ok(const ConvArgs &a)
     if (a.upsample || (a.Hs & 1) || (a.Ws & 1)) return false;
     if (conv_sx_pieces(a.w_interleave)) return false;
     if (a.w_interleave) return conv_ws_planar_ok(a);                    // the wave-specialised kernels (conv_ws.hip)
-    static const bool no_direct = getenv("IPDM_CONV_NO_DIRECT") != nullptr;
-    static const bool no_planar = getenv("IPDM_DIRECT_NO_PLANAR") != nullptr;
-    return !no_direct && !no_planar && conv_direct_eligible(a);
+    // (the stride-2 direct kernel and the 4-wave kernels below read NCHW only)
+    return a.stride == 1 && !opt(OPT_CONV_NO_DIRECT) && !opt(OPT_DIRECT_NO_PLANAR) && conv_direct_eligible(a);
 }
 
 namespace {
@@ -469,13 +466,10 @@ int planar_to_linear_launch(const float *src, float *dst, long planes, int H, in
 
 int conv_weight_interleave(int Cout, int ks, int stride)
 {
-    static const bool legacy = getenv("IPDM_CONV_LEGACY") != nullptr;
-    static const bool legacy1 = getenv("IPDM_CONV1X1_LEGACY") != nullptr;
-    static const bool legacy2 = getenv("IPDM_CONVS2_LEGACY") != nullptr;
-    // IPDM_CONV_SPLIT=3 (6-term, fp32-equivalent) or 2 (3-term): opt-in split-bf16 evaluation of the wide 3x3 stride-1 convs
-    // (read at every pack, not cached: one process may hold nets of both modes -- bench.py's alt leg, the split parity tests)
-    const char *split_env = getenv("IPDM_CONV_SPLIT");
-    const int split = split_env ? atoi(split_env) : 0;
+    const bool legacy = opt(OPT_CONV_LEGACY) != 0, legacy1 = opt(OPT_CONV1X1_LEGACY) != 0, legacy2 = opt(OPT_CONVS2_LEGACY) != 0;
+    // conv_split = 3 (6-term, fp32-equivalent) or 2 (3-term): opt-in split-bf16 evaluation of the wide 3x3 stride-1 convs
+    // (read at every pack: one process may hold nets of both modes -- bench.py's alt leg, the split parity tests)
+    const int split = opt(OPT_CONV_SPLIT);
     if (!legacy && (split == 2 || split == 3) && ks == 3 && stride == 1 && Cout > 32) return 100 + split;
     if (legacy || Cout <= 32 || (ks != 3 && ks != 1) || (ks == 1 && (legacy1 || stride != 1)) || stride > 2 || (stride == 2 && legacy2))
         return 0;

@@ -362,9 +362,9 @@ namespace ipdm {
 
 bool conv_direct_eligible(const ConvArgs &a)
 {
-    static const int max_cin = getenv("IPDM_DIRECT_MAX_CIN") ? atoi(getenv("IPDM_DIRECT_MAX_CIN")) : 160;
+    const int max_cin = opt(OPT_DIRECT_MAX_CIN);
     const int cin = a.C1 + a.C2;
-    static const bool no_s2 = getenv("IPDM_DIRECT_NO_S2") != nullptr;      // A/B: stride 2 on the legacy 4-wave MFMA kernel
+    const bool no_s2 = opt(OPT_DIRECT_NO_S2) != 0;      // A/B: stride 2 on the legacy 4-wave MFMA kernel
     if (a.stride == 2)
         return !no_s2 && a.ksize == 3 && a.Cout <= 16 && cin <= 32 && !a.upsample && !a.x1_planar && a.w_interleave == 0 && a.cout_pad >= 16;
     return (a.ksize == 3 || a.ksize == 1) && a.stride == 1 && a.Cout <= 16 && (cin <= max_cin || (a.Cout <= 4 && cin <= 128)) && a.w_interleave == 0 &&
@@ -374,7 +374,7 @@ bool conv_direct_eligible(const ConvArgs &a)
 // the narrow Upsample convolutions in parity form (w_up2 packed with the plain layout): exact 2x, no prologue, one source
 bool conv_direct_up2_eligible(const ConvArgs &a)
 {
-    const bool off = getenv("IPDM_CONV_NO_UP2") != nullptr;      // (read per call, like conv_up2_eligible)
+    const bool off = opt(OPT_CONV_NO_UP2) != 0;      // (read per call, like conv_up2_eligible)
     return !off && a.w_up2 && a.w_interleave == 0 && a.ksize == 3 && a.stride == 1 && a.C2 == 0 && a.act == 0 && !a.res &&
            !a.x1_planar && a.H == 2 * a.Hs && a.W == 2 * a.Ws && a.Ho == a.H && a.Wo == a.W && a.Cout > 4 && a.Cout <= 16 &&
            a.C1 <= 64 && a.cout_pad >= 16;

@@ -384,7 +384,7 @@ int conv2d_sx_launch(const ConvArgs &a, hipStream_t st)
     // A/B switch: two consumer waves per SIMD (eight waves of 4 accumulators).  Measured equal to one (226 vs 228
     // TFLOP/s-equivalent on 128->128 @512^2): at 66 % matrix-pipe occupancy and 1.7 GHz the kernel sits at 86 % of the
     // 1585 TFLOP/s the chip sustains on a pure bf16 MFMA stream -- the limit is the power-managed clock, not issue bubbles.
-    static const bool cw2 = getenv("IPDM_CONV_SX_CW2") != nullptr;
+    const bool cw2 = opt(OPT_CONV_SX_CW2) != 0;
     if (cw2) {
         if (ns == 3) return wide ? launch_sx<4, 3, 2>(a, st) : launch_sx<2, 3, 2>(a, st);
         return wide ? launch_sx<4, 2, 2>(a, st) : launch_sx<2, 2, 2>(a, st);

@@ -649,7 +649,7 @@ int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
     static_assert(LDS_TOTAL <= 160 * 1024, "conv_ws: LDS stages exceed 160 KiB");
     ConvArgs a = args;
     // IPDM_CONV_DBG=8: in-kernel s_memtime stamps per phase (tools/bench_conv_dbg.py; needs a.dbg_buf, bench entry only)
-    static const int dbg = getenv("IPDM_CONV_DBG") ? atoi(getenv("IPDM_CONV_DBG")) : 0;
+    const int dbg = a.dbg_buf ? opt(OPT_CONV_DBG) : 0;
     a.dbg = a.dbg_buf ? (dbg & 8) : 0;
     a.tiles_x = cdiv(a.Wo, T::TW);
     a.tiles_y = cdiv(a.Ho, T::TH);
@@ -692,7 +692,7 @@ int launch_ws_v(const ConvArgs &args, hipStream_t st, int prof_cls)
 template <int KS, int STRIDE, int MB, int NB, int KC, int IL = MB, int PBW = 32>
 int launch_ws(const ConvArgs &a, hipStream_t st, int prof_cls)
 {
-    static const bool strict = getenv("IPDM_CONV_VEC4_STRICT") != nullptr;     // A/B: rows of whole 4-pixel runs only, as in round 1
+    const bool strict = opt(OPT_CONV_VEC4_STRICT) != 0;     // A/B: rows of whole 4-pixel runs only, as in round 1
     if ((!strict || (a.Wo & 3) == 0) && a.Cout % (32 * MB) == 0) {
         if constexpr (STRIDE == 1 && KS != 2) {       // readers of an up2 convolution's parity-planar output (conv_ws_planar_ok)
             if (a.x1_planar) return launch_ws_v<KS, STRIDE, MB, NB, KC, IL, PBW, true, true>(a, st, prof_cls);
@@ -713,7 +713,7 @@ namespace ipdm {
 // SAMPLE (256 channels at 32x32, 63x29, 32x15: 8-16 tiles).
 int conv_ws_split(const ConvArgs &a)
 {
-    static const bool off = getenv("IPDM_CONV_NO_SPLITK") != nullptr;
+    const bool off = opt(OPT_CONV_NO_SPLITK) != 0;
     if (off || !a.w_interleave || a.w_interleave > 4 || conv_up2_eligible(a)) return 1;
     const long per_sample = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128);
     if (per_sample > 16) return 1;
@@ -728,7 +728,7 @@ int conv_ws_split(const ConvArgs &a)
 // which launches of this file can read x1 parity-planar: the stride-1 kernels with whole cout tiles (launch_ws)
 bool conv_ws_planar_ok(const ConvArgs &a)
 {
-    static const bool strict = getenv("IPDM_CONV_VEC4_STRICT") != nullptr;
+    const bool strict = opt(OPT_CONV_VEC4_STRICT) != 0;
     return (a.w_interleave == 2 || a.w_interleave == 4) && a.stride == 1 && (a.ksize == 1 || a.ksize == 3) &&
            a.Cout % (32 * a.w_interleave) == 0 && (!strict || (a.Wo & 3) == 0) && !conv_up2_eligible(a);
 }
@@ -736,7 +736,7 @@ bool conv_ws_planar_ok(const ConvArgs &a)
 // the up-sampling convolution as four parity convolutions (ConvArgs::w_up2): exact 2x nearest, wide layers, no prologue
 bool conv_up2_eligible(const ConvArgs &a)
 {
-    const bool off = getenv("IPDM_CONV_NO_UP2") != nullptr;      // (read per call: bench.py times both forms in one process)
+    const bool off = opt(OPT_CONV_NO_UP2) != 0;      // (read per call: bench.py times both forms in one process)
     return !off && a.w_up2 && (a.w_interleave == 2 || a.w_interleave == 4) && a.ksize == 3 && a.stride == 1 && a.C2 == 0 &&
            a.act == 0 && !a.res && a.H == 2 * a.Hs && a.W == 2 * a.Ws && a.Ho == a.H && a.Wo == a.W;
 }

@@ -218,7 +218,7 @@ int gn_tiles_launch(const GnTileArgs &a, hipStream_t st)
                  Ctot, a.groups);
     int rows = a.src[0].rows;
     if (a.nsrc > 1 && a.src[1].rows > rows) rows = a.src[1].rows;
-    static const bool two_stage = getenv("IPDM_GN_TWO_STAGE") != nullptr;      // A/B: always the two-launch form
+    const bool two_stage = opt(OPT_GN_TWO_STAGE) != 0;      // A/B: always the two-launch form
     const int cpg = Ctot / a.groups;
     if (!two_stage && cpg <= 256 && (long)rows * cpg <= GN_ONE_LAUNCH_MAX) {
         hipLaunchKernelGGL(gn_group_kernel, dim3(a.groups, a.B), dim3(256), 0, st, a);

@@ -375,7 +375,8 @@ struct ipdm_unet {
     int temb_rows = 0;
     int max_gn_groups = 32, max_ch = 0;
     bool transposed = false;                    // this forward runs on [B,C,W,H] activations (run_forward: orientation)
-    bool no_fused_stats = false;                // IPDM_GN_UNFUSED=1: GroupNorm statistics by a pass over the activations (gn_partial)
+    bool no_fused_stats = false;                // option gn_unfused: GroupNorm statistics by a pass over the activations (gn_partial)
+    int opts[OPT_COUNT] = {};                   // the option table as it stood at ipdm_unet_create (weights were packed under it)
 
     // forward state
     Arena arena;
@@ -396,6 +397,7 @@ struct ipdm_unet {
     };
     std::map<GraphKey, hipGraphExec_t> graphs;
     std::map<GraphKey, int> graph_seen;
+    std::map<GraphKey, size_t> graph_need;      // workspace bytes the captured walk addresses
 };
 
 namespace {
@@ -476,6 +478,7 @@ extern "C" int ipdm_unet_create(const ipdm_unet_cfg *cfg, const float *const *we
     IPDM_REQUIRE(cfg_ok(cfg) && weights && out, "unet_create: bad argument");
     IPDM_REQUIRE(cfg->model_channels % 2 == 0, "unet_create: model_channels must be even");
     ipdm_unet *net = new ipdm_unet();
+    opt_snapshot(net->opts);
     net->cfg = *cfg;
     net->topo = build_topology(*cfg);
     auto plist = list_params(*cfg, net->topo);
@@ -817,7 +820,7 @@ size_t fixed_ws_bytes(const ipdm_unet *net, int B)
 // orientation wastes at least 2 % less.  IPDM_UNET_TRANSPOSE=0/1 forces the choice.
 bool choose_transposed(const ipdm_unet *net, int H, int W)
 {
-    if (const char *e = getenv("IPDM_UNET_TRANSPOSE")) return atoi(e) != 0;
+    if (const int force = opt(OPT_UNET_TRANSPOSE); force >= 0) return force != 0;
     if (H == W) return false;
     double cost[2] = {0.0, 0.0};
     int h = H, w = W;
@@ -837,8 +840,13 @@ bool choose_transposed(const ipdm_unet *net, int H, int W)
 int run_forward(ipdm_unet *net, const float *d_x, int t, float *d_eps, int B, int H, int W, void *d_ws, size_t ws_bytes,
                 hipStream_t st, bool dry, size_t *need)
 {
+    // an option that shaped the packed weights or the kernel choice may not change under a live handle
+    if (const int ch = opt_changed_since(net->opts); ch >= 0) {
+        set_error("unet_forward: option '%s' changed after ipdm_unet_create (was %d): create the network again", opt_name(ch), net->opts[ch]);
+        return IPDM_ERR_INVALID;
+    }
     net->B = B; net->st = st; net->dry = dry; net->ws = (char *)d_ws;
-    net->no_fused_stats = getenv("IPDM_GN_UNFUSED") != nullptr;
+    net->no_fused_stats = opt(OPT_GN_UNFUSED) != 0;
     const size_t fixed = fixed_ws_bytes(net, B);
     if (!dry && ws_bytes < fixed) { set_error("unet_forward: workspace too small"); return IPDM_ERR_WORKSPACE; }
     // fixed region
@@ -849,6 +857,12 @@ int run_forward(ipdm_unet *net, const float *d_x, int t, float *d_eps, int B, in
     net->gn_scale = (float *)w; w += align_up(((size_t)B * net->max_ch + 64) * sizeof(float), 256);
     net->gn_shift = (float *)w; w += align_up(((size_t)B * net->max_ch + 64) * sizeof(float), 256);
     net->gn_part = (double *)w;
+    if (!dry) {
+        // the convolutions' prologue reads a K chunk past [B, C] without selects (channels beyond Cin carry zero weights,
+        // but NaN * 0 is NaN): the read-ahead floats are zeroed, once per forward
+        (void)hipMemsetAsync(net->gn_scale + (size_t)B * net->max_ch, 0, 64 * sizeof(float), st);
+        (void)hipMemsetAsync(net->gn_shift + (size_t)B * net->max_ch, 0, 64 * sizeof(float), st);
+    }
     net->ws = (char *)d_ws + fixed;
     net->arena.reset(dry ? (size_t)1 << 46 : ws_bytes - fixed);
     for (Tensor *tt : net->live) delete tt;
@@ -951,18 +965,30 @@ extern "C" int ipdm_unet_forward_graph(ipdm_unet *net, const float *d_x, int32_t
     IPDM_REQUIRE(net && d_x && d_eps && d_ws && B > 0 && H > 0 && W > 0 && t >= 0, "unet_forward_graph: bad argument");
     hipStream_t st = (hipStream_t)stream;
     if (prof_enabled() || !st) return run_forward(net, d_x, t, d_eps, B, H, W, d_ws, ws_bytes, st, false, nullptr);   // (the legacy default stream cannot capture)
-    const int mode = (getenv("IPDM_GN_UNFUSED") ? 1 : 0) | (getenv("IPDM_UNET_TRANSPOSE") ? 2 + 4 * (atoi(getenv("IPDM_UNET_TRANSPOSE")) != 0) : 0);
+    if (const int ch = opt_changed_since(net->opts); ch >= 0) {
+        set_error("unet_forward_graph: option '%s' changed after ipdm_unet_create", opt_name(ch));
+        return IPDM_ERR_INVALID;
+    }
+    // every per-call switch that changes the recorded launches is part of the key
+    const int mode = (opt(OPT_GN_UNFUSED) ? 1 : 0) | ((opt(OPT_UNET_TRANSPOSE) + 1) << 1) | (opt(OPT_CONV_NO_UP2) ? 8 : 0) |
+                     (opt(OPT_GN_TWO_STAGE) ? 16 : 0) | (opt(OPT_ATTN_NO_ZSEQ) ? 32 : 0);
     const ipdm_unet::GraphKey key{t, B, H, W, d_x, d_eps, d_ws, mode};
     auto it = net->graphs.find(key);
     if (it != net->graphs.end()) {
+        // the recorded launches address the workspace as it was walked at capture time: same pointer (key), and it must
+        // still be as large as that walk needs
+        IPDM_REQUIRE(ws_bytes >= net->graph_need[key], "unet_forward_graph: workspace smaller (%zu) than at capture (%zu)", ws_bytes,
+                     net->graph_need[key]);
         IPDM_HIP_CHECK(hipGraphLaunch(it->second, st));
         return IPDM_OK;
     }
+    if (net->graph_seen.size() >= 1024) net->graph_seen.clear();      // callers that pass fresh buffers every time never capture
     if (net->graph_seen[key]++ == 0) return run_forward(net, d_x, t, d_eps, B, H, W, d_ws, ws_bytes, st, false, nullptr);
     if (net->graphs.size() >= 256) {            // buffers keep changing under the caller: start over rather than grow
         for (auto &kv : net->graphs) (void)hipGraphExecDestroy(kv.second);
         net->graphs.clear();
         net->graph_seen.clear();
+        net->graph_need.clear();
     }
     hipGraph_t graph = nullptr;
     IPDM_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -978,6 +1004,11 @@ extern "C" int ipdm_unet_forward_graph(ipdm_unet *net, const float *d_x, int32_t
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { set_error("unet_forward_graph: instantiate failed: %s", hipGetErrorString(ei)); return IPDM_ERR_HIP; }
     net->graphs[key] = exec;
+    {
+        size_t need = 0;
+        run_forward(net, nullptr, 0, nullptr, B, H, W, nullptr, 0, nullptr, true, &need);
+        net->graph_need[key] = need;
+    }
     IPDM_HIP_CHECK(hipGraphLaunch(exec, st));
     return IPDM_OK;
 }
@@ -1010,8 +1041,10 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
         IPDM_HIP_CHECK(hipMalloc((void **)&d_be, Cin * sizeof(float)));
         IPDM_HIP_CHECK(hipMemcpy(d_g, gamma_host, Cin * sizeof(float), hipMemcpyHostToDevice));
         IPDM_HIP_CHECK(hipMemcpy(d_be, beta_host, Cin * sizeof(float), hipMemcpyHostToDevice));
-        IPDM_HIP_CHECK(hipMalloc((void **)&d_sc, ((size_t)B * Cin + 64) * sizeof(float)));      // (+ a K chunk of read-ahead)
-        IPDM_HIP_CHECK(hipMalloc((void **)&d_sh, ((size_t)B * Cin + 64) * sizeof(float)));
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_sc, ((size_t)B * Cin + 64) * sizeof(float)));      // (+ a K chunk of read-ahead,
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_sh, ((size_t)B * Cin + 64) * sizeof(float)));      //  zeroed: NaN * 0 weight = NaN)
+        IPDM_HIP_CHECK(hipMemsetAsync(d_sc + (size_t)B * Cin, 0, 64 * sizeof(float), st));
+        IPDM_HIP_CHECK(hipMemsetAsync(d_sh + (size_t)B * Cin, 0, 64 * sizeof(float), st));
         IPDM_HIP_CHECK(hipMalloc((void **)&d_part, gn_partials_bytes(B, groups)));
         GnArgs g;
         g.x1 = d_x1; g.x2 = d_x2; g.C1 = C1; g.C2 = C2; g.B = B; g.HW = (long)Hs * Ws; g.groups = groups;
@@ -1064,6 +1097,7 @@ extern "C" int ipdm_op_up_conv_chain(const float *d_x, int32_t C, int32_t B, int
         void *d = nullptr;
         IPDM_HIP_CHECK(hipMalloc(&d, bytes ? bytes : 4));
         if (h) IPDM_HIP_CHECK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+        else IPDM_HIP_CHECK(hipMemset(d, 0, bytes ? bytes : 4));      // (scale / shift read-ahead padding must not hold NaNs)
         tofree.push_back(d);
         *out = d;
         return IPDM_OK;
@@ -1147,6 +1181,7 @@ extern "C" int ipdm_op_conv_gn_conv(const float *d_x, int32_t C, int32_t B, int3
         void *d = nullptr;
         IPDM_HIP_CHECK(hipMalloc(&d, bytes ? bytes : 4));
         if (h) IPDM_HIP_CHECK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+        else IPDM_HIP_CHECK(hipMemset(d, 0, bytes ? bytes : 4));      // (scale / shift read-ahead padding must not hold NaNs)
         tofree.push_back(d);
         *out = d;
         return IPDM_OK;
@@ -1224,6 +1259,8 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     IPDM_HIP_CHECK(hipMalloc((void **)&d_sc, ((size_t)B * Cin + 64) * 4));
     IPDM_HIP_CHECK(hipMalloc((void **)&d_sh, ((size_t)B * Cin + 64) * 4));
     IPDM_HIP_CHECK(hipMalloc((void **)&d_b, (size_t)Cout * 4));
+    IPDM_HIP_CHECK(hipMemset(d_sc + (size_t)B * Cin, 0, 64 * 4));
+    IPDM_HIP_CHECK(hipMemset(d_sh + (size_t)B * Cin, 0, 64 * 4));
     ipdm_randn(d_sc, 1, (int64_t)B * Cin, 4, 0, 0, nullptr);
     ipdm_randn(d_sh, 1, (int64_t)B * Cin, 5, 0, 0, nullptr);
     ipdm_randn(d_b, 1, Cout, 6, 0, 0, nullptr);
@@ -1236,7 +1273,7 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     if (conv_split_ws_bytes(a)) IPDM_HIP_CHECK(hipMalloc((void **)&d_split, conv_split_ws_bytes(a)));
     a.split_ws = d_split;
     int rc = 0;
-    const bool stamps = getenv("IPDM_CONV_DBG") && (atoi(getenv("IPDM_CONV_DBG")) & 8);
+    const bool stamps = (opt(OPT_CONV_DBG) & 8) != 0;
     if (stamps) { IPDM_HIP_CHECK(hipMalloc((void **)&a.dbg_buf, 4096 * 8 * 8)); IPDM_HIP_CHECK(hipMemset(a.dbg_buf, 0, 4096 * 8 * 8)); }
     for (int i = 0; i < 3 && !rc; ++i) rc = conv2d_launch(a, nullptr);
     hipEvent_t e0, e1;

@@ -73,3 +73,15 @@ def test_errors_are_status_codes_not_exceptions():
     assert rc < 0 and lib.ipdm_last_error()
     with pytest.raises(_lib.IpdmError):
         _lib.call("ipdm_cosine_lambda", 0, 1.0, 0, C.byref(C.c_double()))
+
+
+def test_options_table_without_a_gpu():
+    """ipdm_set_option / ipdm_get_option are host-only: defaults, the IPDM_ prefix alias, unknown names."""
+    from ipdm_pytorch_amd import _lib
+    assert _lib.get_option("conv_split") == 0 and _lib.get_option("direct_max_cin") == 160 and _lib.get_option("unet_transpose") == -1
+    with _lib.option("conv_no_up2", 1):
+        assert _lib.get_option("IPDM_CONV_NO_UP2") == 1
+    assert _lib.get_option("conv_no_up2") == 0
+    import pytest
+    with pytest.raises(_lib.IpdmError, match="unknown option"):
+        _lib.set_option("no_such_switch", 1)

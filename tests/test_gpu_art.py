@@ -61,15 +61,15 @@ def test_project_small_vs_oracle():
 
 @pytest.mark.parametrize("per_view", [False, True])
 @pytest.mark.parametrize("nsart,ntv", [(1, 0), (3, 0), (3, 2)])
-def test_reconstruct_small_vs_oracle(nsart, ntv, per_view, monkeypatch):
+def test_reconstruct_small_vs_oracle(nsart, ntv, per_view):
     """Both forms of a sweep: the one-launch grid-resident kernel (default when the grid fits the chip) and one launch
-    per view (IPDM_ART_PER_VIEW=1, read at plan creation; also what larger grids fall back to)."""
-    if per_view:
-        monkeypatch.setenv("IPDM_ART_PER_VIEW", "1")
+    per view (option art_per_view, read at plan creation; also what larger grids fall back to)."""
+    from ipdm_pytorch_amd import _lib
     g, go, lut, betas = _small()
     vol = _phantoms(3, g.nx)
     proj = oa.project(go, lut, betas, vol)
-    plan = art.ArtPlan(lut, betas, device=DEV, geom=g)
+    with _lib.option("art_per_view", 1 if per_view else 0):
+        plan = art.ArtPlan(lut, betas, device=DEV, geom=g)
     got = plan.reconstruct_device(torch.from_numpy(proj), nsart, ntv).cpu().numpy()
     want = oa.reconstruct(go, lut, betas, proj, nsart, ntv, permute=False)
     err, scale = np.abs(got - want), np.abs(want).max()
@@ -104,12 +104,9 @@ def test_reconstruct_bit_reproducible_and_per_slice():
     a = plan.reconstruct_device(proj, 2, 1)
     b = plan.reconstruct_device(proj, 2, 1)
     assert torch.equal(a, b)
-    import os
-    os.environ["IPDM_ART_PER_VIEW"] = "1"              # the per-view form computes the same bits
-    try:
+    from ipdm_pytorch_amd import _lib
+    with _lib.option("art_per_view", 1):              # the per-view form computes the same bits
         plan2 = art.ArtPlan(lut, betas, device=DEV, geom=g)
-    finally:
-        del os.environ["IPDM_ART_PER_VIEW"]
     assert torch.equal(plan2.reconstruct_device(proj, 2, 1), a)
     for i in (0, 7, 9):
         assert torch.equal(plan.reconstruct_device(proj[i:i + 1], 2, 1), a[i:i + 1])

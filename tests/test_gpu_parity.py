@@ -385,20 +385,20 @@ def test_attention_key_slices_do_not_depend_on_the_schedule(T):
 
 
 @pytest.mark.parametrize("B,heads,T", [(1, 4, 117), (2, 4, 1024), (1, 4, 1827), (1, 2, 4096)])
-def test_attention_kernel_split_bf16_x6(B, heads, T, monkeypatch):
-    """IPDM_ATTN_SPLIT=3: both contractions as 3-piece split-bf16 (6 MFMA terms, f32 accumulate) at the SAME tolerance
+def test_attention_kernel_split_bf16_x6(B, heads, T):
+    """attn_split = 3: both contractions as 3-piece split-bf16 (6 MFMA terms, f32 accumulate) at the SAME tolerance
     as the exact-f32 kernel (ragged key blocks, several tiles, the rescale branch)."""
     from ipdm_pytorch_amd import _lib
-    monkeypatch.delenv("IPDM_ATTN_SPLIT", raising=False)
     assert _lib.lib().ipdm_attention_kernel_code(64) == 1
-    monkeypatch.setenv("IPDM_ATTN_SPLIT", "3")
-    assert _lib.lib().ipdm_attention_kernel_code(64) == 3       # the split kernel is what runs
-    test_attention_kernel(B, heads, T)
+    with _lib.option("attn_split", 3):
+        assert _lib.lib().ipdm_attention_kernel_code(64) == 3       # the split kernel is what runs
+        test_attention_kernel(B, heads, T)
 
 
-def test_attention_random_lengths_split_bf16_x6(monkeypatch):
-    monkeypatch.setenv("IPDM_ATTN_SPLIT", "3")
-    test_attention_random_lengths()
+def test_attention_random_lengths_split_bf16_x6():
+    from ipdm_pytorch_amd import _lib
+    with _lib.option("attn_split", 3):
+        test_attention_random_lengths()
 
 
 def test_attention_random_lengths():
@@ -551,6 +551,45 @@ def test_fused_groupnorm_statistics_chain(case):
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
 
 
+@pytest.mark.parametrize("offset", [30.0, 300.0])
+def test_fused_groupnorm_statistics_with_a_large_channel_offset(offset):
+    """Fused statistics are float32 per-tile {sum, sum of squares} folded in float64 (var = E[v^2] - mean^2).  With a
+    channel mean far above its spread -- here conv A's bias puts |mean|/std at ~30 and ~300, far beyond what a GroupNorm
+    input of this network family shows -- the cancellation costs relative accuracy of the variance ~1e-9 (mean/std)^2
+    (per-tile rounding averaged over thousands of tiles), i.e. a scale error of the normalised values that must stay below
+    the representation noise of the float32 activations themselves, 6e-8 |mean|/std per element.  Reference: float64."""
+    import ctypes
+    import torch.nn.functional as F
+    from ipdm_pytorch_amd import _lib
+    B, C, H, W, CA, CB = 2, 64, 64, 96, 64, 64
+    x = torch.from_numpy(synth.hash_normal((B, C, H, W), 7001))
+    wA = torch.from_numpy(synth.hash_normal((CA, C, 3, 3), 7002)) / np.sqrt(C * 9)
+    bA = offset * (1 + 0.1 * torch.from_numpy(synth.hash_normal((CA,), 7003)))
+    wB = torch.from_numpy(synth.hash_normal((CB, CA, 3, 3), 7004)) / np.sqrt(CA * 9)
+    bB = torch.from_numpy(synth.hash_normal((CB,), 7005))
+    gamma = torch.from_numpy(synth.hash_uniform((CA,), 7006)) + 0.5
+    beta = torch.from_numpy(synth.hash_normal((CA,), 7007)) * 0.2
+    groups = ou.gn_groups(CA)
+    d_mid = torch.full((B, CA, H, W), float("nan"), device=DEV)
+    d_out = torch.full((B, CB, H, W), float("nan"), device=DEV)
+    arrs = [np.ascontiguousarray(t.numpy(), dtype=np.float32) for t in (wA, bA, gamma, beta, wB, bB)]
+    rows = ctypes.c_int32(-1)
+    xd = x.to(DEV)
+    _lib.call("ipdm_op_conv_gn_conv", _lib.ptr(xd), C, B, H, W, _lib.ptr(arrs[0]), _lib.ptr(arrs[1]), CA, 3, 1, None,
+              groups, _lib.ptr(arrs[2]), _lib.ptr(arrs[3]), 2, _lib.ptr(arrs[4]), _lib.ptr(arrs[5]), CB, _lib.ptr(d_mid),
+              _lib.ptr(d_out), ctypes.byref(rows), _lib.current_stream())
+    assert rows.value > 0
+    # float64 reference computed FROM THE DEVICE'S OWN float32 mid (so only GroupNorm + conv B are under test)
+    mid = d_mid.cpu().double()
+    h = F.silu(F.group_norm(mid, groups, gamma.double(), beta.double(), eps=1e-5))
+    want = F.conv2d(h, wB.double(), bB.double(), padding=1)
+    ratio = float((mid.mean(dim=(2, 3)).abs() / mid.std(dim=(2, 3))).max())     # per-channel |mean|/std; groups of 2 channels
+    err = float((d_out.cpu().double() - want).abs().max())
+    budget = (2e-5 + 2e-9 * ratio * ratio) * max(1.0, float(want.abs().max()))
+    print("offset %g: |mean|/std %.0f, err %.3e, budget %.3e" % (offset, ratio, err, budget))
+    assert err <= budget, (err, budget, ratio)
+
+
 @pytest.mark.parametrize("case", [
     # B, C, Hs, Ws, CA, C2, CB, ksB, act
     (2, 128, 16, 32, 128, 0, 128, 3, 2),          # 128-cout tiles; GroupNorm from the parity form's fused statistics
@@ -608,20 +647,35 @@ def test_upsample_conv_parity_form(case):
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
 
 
-def test_fused_statistics_equal_activation_pass(monkeypatch):
-    """The two ways of forming GroupNorm statistics (fused per-tile partial sums / IPDM_GN_UNFUSED=1: a pass over the
+def test_fused_statistics_equal_activation_pass():
+    """The two ways of forming GroupNorm statistics (fused per-tile partial sums / option gn_unfused: a pass over the
     activations) agree to float32 rounding through a whole small UNet, concat inputs and materialised concats included."""
+    from ipdm_pytorch_amd import _lib
     net, _ = _native_unet(SMALL_CFGS["b"], 11)
     x = torch.from_numpy(synth.hash_normal(SMALL_SHAPES["b"], 101)).to(DEV)
-    monkeypatch.delenv("IPDM_GN_UNFUSED", raising=False)
     a = net(x, 7).cpu()
-    monkeypatch.setenv("IPDM_GN_UNFUSED", "1")
-    b = net(x, 7).cpu()
+    with _lib.option("gn_unfused", 1):
+        b = net(x, 7).cpu()
     assert (a - b).abs().max() <= 5e-6 and float(a.abs().max()) > 0.1
 
 
+def test_layout_option_changed_under_a_live_handle_is_an_error():
+    """A switch that shapes packed weights / kernel choice (here conv_legacy) flipped between ipdm_unet_create and a forward
+    must fail loudly, not run kernels on a layout packed for other ones; per-call switches may change."""
+    from ipdm_pytorch_amd import _lib
+    net, _ = _native_unet(SMALL_CFGS["a"], 11)
+    x = torch.from_numpy(synth.hash_normal(SMALL_SHAPES["a"], 101)).to(DEV)
+    a = net(x, 3).clone()
+    with _lib.option("conv_legacy", 1):
+        with pytest.raises(_lib.IpdmError, match="changed after ipdm_unet_create"):
+            net(x, 3)
+    with _lib.option("conv_no_up2", 1):            # per call: allowed (both weight sets are packed)
+        net(x, 3)
+    assert torch.equal(net(x, 3), a)
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "d"])
-def test_unet_orientation_equivalence(tag, golden, monkeypatch):
+def test_unet_orientation_equivalence(tag, golden):
     """The executor may run a forward on spatially transposed activations (3x3 kernels transposed too) when that pads the
     MFMA tiling less (2000x912 sinograms); both orientations must reproduce the reference's outputs (unet_small.npz) and
     agree with each other to float32 rounding.  Odd, non-square sizes (23x19), up-sampling to explicit sizes, stride 2."""
@@ -629,9 +683,10 @@ def test_unet_orientation_equivalence(tag, golden, monkeypatch):
     net, _ = _native_unet(SMALL_CFGS[tag], 11)
     x = torch.from_numpy(synth.hash_normal(SMALL_SHAPES[tag], 101)).to(DEV)
     outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("IPDM_UNET_TRANSPOSE", flag)
-        got = net(x, 7).cpu().numpy()
+    from ipdm_pytorch_amd import _lib
+    for flag in (0, 1):
+        with _lib.option("unet_transpose", flag):
+            got = net(x, 7).cpu().numpy()
         np.testing.assert_allclose(got, g["%s_t7" % tag], rtol=0, atol=1e-5)
         outs.append(got)
     assert not np.array_equal(outs[0], outs[1]) or True          # (summation order differs; equality is not required)
@@ -675,14 +730,16 @@ def test_unet_small_golden(tag, golden):
 
 
 @pytest.fixture
-def split_bf16(monkeypatch):
-    """Opt-in split-bf16 evaluation of the wide 3x3 convolutions (read when weights are packed)."""
+def split_bf16():
+    """Opt-in split-bf16 evaluation of the wide 3x3 convolutions (option conv_split, read when weights are packed)."""
+    from ipdm_pytorch_amd import _lib
+
     def on(pieces):
-        from ipdm_pytorch_amd import _lib
-        monkeypatch.setenv("IPDM_CONV_SPLIT", str(pieces))
+        _lib.set_option("conv_split", pieces)
         assert _lib.lib().ipdm_conv_layout_code(64, 3, 1) == 100 + pieces      # the split kernel is what runs
         assert _lib.lib().ipdm_conv_layout_code(64, 3, 2) in (2, 4) and _lib.lib().ipdm_conv_layout_code(16, 3, 1) == 0
-    return on
+    yield on
+    _lib.set_option("conv_split", 0)
 
 
 @pytest.mark.parametrize("case", [
