@@ -235,7 +235,7 @@ def main():
     roofline = None
     extra = {}
     if prof:
-        fl, ms, nl = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int64 * 3)()
+        fl, ms, nl = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int64 * 4)()
         _lib.call("ipdm_profile_end", C.byref(fl), C.byref(ms), C.byref(nl))
         if nl[0]:
             ach = fl[0] / (ms[0] * 1e-3) / 1e12

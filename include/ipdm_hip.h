@@ -41,8 +41,9 @@ int ipdm_abi_version(void);
  * (-1 | 0 | 1) ...; README.md lists them.  Every switch starts from the environment variable IPDM_<NAME> (read once, kept
  * as a debug alias) and changes only through this call afterwards.  Switches that shape packed weights or kernel choice
  * are recorded by ipdm_unet_create: a forward on a handle created under other values fails with IPDM_ERR_INVALID instead
- * of running on a mismatched layout; per-call switches (conv_no_up2, gn_two_stage, attn_no_zseq, conv_dbg,
- * art_per_view) may change under a live handle.  Returns IPDM_ERR_INVALID for an unknown name. */
+ * of running on a mismatched layout; per-call switches (conv_no_up2, conv_no_wino, gn_unfused, gn_two_stage,
+ * unet_transpose, attn_no_zseq, conv_dbg, art_per_view: every weight form they choose between is packed, the workspace
+ * need is re-queried per forward) may change under a live handle.  Returns IPDM_ERR_INVALID for an unknown name. */
 int ipdm_set_option(const char *name, int value);
 int ipdm_get_option(const char *name, int *value);
 
@@ -256,8 +257,9 @@ int ipdm_art_project(ipdm_art_plan *plan, const float *d_volume, float *d_proj, 
 /* ------------------------------------------------------------------ measurement ------------- */
 /* Per-launch HIP-event timing of the hot kernels on their launch stream (bench.py roofline leg; no
  * reference counterpart -- the reference has no profiling).  Classes: 0 = conv 3x3
- * stride-1 wide tile (dominant kernel), 1 = other conv variants, 2 = attention.  ipdm_profile_end needs
- * the stream synchronised; outputs are arrays of 3. */
+ * stride-1 wide tile in its direct form, 1 = other conv variants, 2 = attention, 3 = the Winograd-domain form of
+ * class 0's layers (recorded with its EXECUTED flops, 16/36 of the 3x3 count).  ipdm_profile_end needs the stream
+ * synchronised; outputs are arrays of 4. */
 int ipdm_profile_begin(int32_t max_launches);
 int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches);
 

@@ -796,6 +796,7 @@ int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
         if (a.w_interleave == 4) return launch_ws<2, 1, 4, 2, 8>(k, st, 1);
         return launch_ws<2, 1, 2, 4, 8>(k, st, 1);
     }
+    if (conv_wino_eligible(a)) return conv2d_wino_launch(a, st);      // the Winograd-domain form (conv_wino.hip)
     const int S = a.split_ws ? conv_ws_split(a) : 1;
     if (S == 1) return conv2d_ws_dispatch(a, st);
     ConvArgs k = a;

@@ -310,7 +310,8 @@ namespace {
 // a forward on spatially TRANSPOSED activations (run_forward: orientation)
 // w_up2 / w_up2_t: the Upsample convolutions' parity form (conv_pack_weights_up2), null elsewhere
 struct ConvP { float *w = nullptr; float *w_t = nullptr; float *b = nullptr; int cin = 0, cout = 0, ks = 0, cout_pad = 0, interleave = 0;
-               float *w_up2 = nullptr, *w_up2_t = nullptr; };
+               float *w_up2 = nullptr, *w_up2_t = nullptr;
+               float *w_wino = nullptr, *w_wino_t = nullptr; };      // Winograd-domain weights (conv_pack_weights_wino), both orientations
 struct NormP { float *g = nullptr, *b = nullptr; int ch = 0, groups = 0; };
 struct ResP { NormP n1, n2; ConvP c1, c2, sc; bool has_sc = false; int bias_off = 0; };   // bias_off into bias_eff
 struct AttnP { NormP n; ConvP qkv, proj; };
@@ -442,6 +443,12 @@ int make_conv(ipdm_unet *net, const WeightMap &wm, const std::string &wname, con
         conv_pack_weights(wt.data(), cout, cin, ks, out.interleave, packed, cin_pad, cout_pad);
         rc = upload(net, packed.data(), packed.size(), &out.w_t);
         if (rc) return rc;
+        if (!up && conv_wino_shape_ok(cout, cin, ks, stride, out.interleave)) {
+            conv_pack_weights_wino(w, cout, cin, packed);
+            if ((rc = upload(net, packed.data(), packed.size(), &out.w_wino))) return rc;
+            conv_pack_weights_wino(wt.data(), cout, cin, packed);
+            if ((rc = upload(net, packed.data(), packed.size(), &out.w_wino_t))) return rc;
+        }
         if (up && (out.interleave == 2 || out.interleave == 4 || (out.interleave == 0 && cout <= 16))) {      // Upsample: the parity form of both orientations
             conv_pack_weights_up2(w, cout, cin, out.interleave, packed);
             if ((rc = upload(net, packed.data(), packed.size(), &out.w_up2))) return rc;
@@ -659,6 +666,7 @@ struct Fwd {
         a.w_interleave = cp.interleave; a.cout_pad = cp.cout_pad;
         a.Hs = x1->H; a.Ws = x1->W; a.H = H; a.W = W; a.upsample = (H != x1->H || W != x1->W); a.act = act; a.res = res ? (const float *)(uintptr_t)256 : nullptr;
         a.w_up2 = net->transposed ? cp.w_up2_t : cp.w_up2;
+        a.w_wino = net->transposed ? cp.w_wino_t : cp.w_wino;
         // parity-planar sources (outputs of up2 convolutions): x1 of the kernels that can read them, converted otherwise
         Tensor *lin1 = nullptr, *lin2 = linear_copy(x2), *linr = linear_copy(res);
         if (x1->planar && !conv_planar_ok(a)) lin1 = linear_copy(x1);
@@ -1013,6 +1021,18 @@ extern "C" int ipdm_unet_forward_graph(ipdm_unet *net, const float *d_x, int32_t
     return IPDM_OK;
 }
 
+// the Winograd-domain weights of a test / benchmark layer, when its shape can use them (device pointer in *out, else null)
+static int upload_wino(const float *w_host, int Cout, int Cin, int ks, int stride, int interleave, float **out)
+{
+    *out = nullptr;
+    if (!conv_wino_shape_ok(Cout, Cin, ks, stride, interleave)) return IPDM_OK;
+    std::vector<float> u;
+    conv_pack_weights_wino(w_host, Cout, Cin, u);
+    IPDM_HIP_CHECK(hipMalloc((void **)out, u.size() * sizeof(float)));
+    IPDM_HIP_CHECK(hipMemcpy(*out, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
+    return IPDM_OK;
+}
+
 // ------------------------------------------------------------------------------------ op-level entry (tests)
 extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, int32_t C2, int32_t B, int32_t Hs, int32_t Ws,
                               int32_t H, int32_t W, const float *w_host, const float *b_host, int32_t Cout, int32_t ksize,
@@ -1026,8 +1046,9 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
     int cin_pad, cout_pad;
     const int interleave = conv_weight_interleave(Cout, ksize, stride);
     conv_pack_weights(w_host, Cout, Cin, ksize, interleave, packed, cin_pad, cout_pad);
-    float *d_w = nullptr, *d_b = nullptr, *d_g = nullptr, *d_be = nullptr, *d_sc = nullptr, *d_sh = nullptr, *d_split = nullptr;
+    float *d_w = nullptr, *d_b = nullptr, *d_g = nullptr, *d_be = nullptr, *d_sc = nullptr, *d_sh = nullptr, *d_split = nullptr, *d_wino = nullptr;
     double *d_part = nullptr;
+    if (int rcw = upload_wino(w_host, Cout, Cin, ksize, stride, interleave, &d_wino)) return rcw;
     IPDM_HIP_CHECK(hipMalloc((void **)&d_w, packed.size() * sizeof(float)));
     IPDM_HIP_CHECK(hipMemcpy(d_w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
     if (b_host) {
@@ -1057,7 +1078,7 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
         a.x1 = d_x1; a.x2 = d_x2; a.C1 = C1; a.C2 = C2; a.B = B; a.Hs = Hs; a.Ws = Ws; a.H = H; a.W = W;
         a.upsample = (H != Hs || W != Ws);
         a.scale_y = (float)Hs / (float)H; a.scale_x = (float)Ws / (float)W;
-        a.w = d_w; a.cout_pad = cout_pad; a.w_interleave = interleave; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
+        a.w = d_w; a.w_wino = d_wino; a.cout_pad = cout_pad; a.w_interleave = interleave; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
         a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
         a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
         a.tiles_x = a.tiles_y = a.co_tiles = 0;
@@ -1067,7 +1088,7 @@ extern "C" int ipdm_op_conv2d(const float *d_x1, int32_t C1, const float *d_x2, 
     }
     IPDM_HIP_CHECK(hipStreamSynchronize(st));
     (void)hipFree(d_split);
-    (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_g); (void)hipFree(d_be); (void)hipFree(d_sc); (void)hipFree(d_sh);
+    (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_g); (void)hipFree(d_be); (void)hipFree(d_sc); (void)hipFree(d_sh); (void)hipFree(d_wino);
     (void)hipFree(d_part);
     return rc;
 }
@@ -1148,6 +1169,10 @@ extern "C" int ipdm_op_up_conv_chain(const float *d_x, int32_t C, int32_t B, int
         b.scale_y = b.scale_x = 1.f; b.w = d_wB; b.cout_pad = coutpB; b.w_interleave = ilB; b.bias = d_bB; b.Cout = CB; b.ksize = ksB;
         b.stride = 1; b.Ho = H; b.Wo = W; b.act = act; b.gn_scale = d_sc; b.gn_shift = d_sh; b.res = nullptr; b.out = d_out;
         b.tiles_x = b.tiles_y = b.co_tiles = 0;
+        float *d_wino = nullptr;
+        if (!rc) rc = upload_wino(wB_host, CB, Cc, ksB, 1, ilB, &d_wino);
+        if (d_wino) tofree.push_back(d_wino);
+        b.w_wino = d_wino;
         if (up2 && !conv_planar_ok(b)) {      // a reader that takes NCHW only: convert, as the executor does
             rc = dev(nullptr, (size_t)B * CA * H * W * 4, (void **)&d_lin);
             if (!rc) rc = planar_to_linear_launch(d_pl, d_lin, (long)B * CA, H, W, st);
@@ -1202,6 +1227,12 @@ extern "C" int ipdm_op_conv_gn_conv(const float *d_x, int32_t C, int32_t B, int3
     a.scale_y = a.scale_x = 1.f; a.w = d_wA; a.cout_pad = coutpA; a.w_interleave = ilA; a.bias = d_bA; a.Cout = CA; a.ksize = ksA;
     a.stride = strideA; a.Ho = Hm; a.Wo = Wm; a.act = 0; a.gn_scale = a.gn_shift = nullptr; a.res = d_resA; a.out = d_mid;
     a.tiles_x = a.tiles_y = a.co_tiles = 0;
+    float *d_winoA = nullptr, *d_winoB = nullptr;
+    if (!rc) rc = upload_wino(wA_host, CA, C, ksA, strideA, ilA, &d_winoA);
+    if (d_winoA) tofree.push_back(d_winoA);
+    if (!rc) rc = upload_wino(wB_host, CB, CA, 3, 1, ilB, &d_winoB);
+    if (d_winoB) tofree.push_back(d_winoB);
+    a.w_wino = d_winoA;
     if (!rc && conv_split_ws_bytes(a)) { float *d_sp; rc = dev(nullptr, conv_split_ws_bytes(a), (void **)&d_sp); if (!rc) a.split_ws = d_sp; }
     const int rows = conv_stats_rows(a);
     if (fused_rows) *fused_rows = rows;
@@ -1228,6 +1259,7 @@ extern "C" int ipdm_op_conv_gn_conv(const float *d_x, int32_t C, int32_t B, int3
         b.scale_y = b.scale_x = 1.f; b.w = d_wB; b.cout_pad = coutpB; b.w_interleave = ilB; b.bias = d_bB; b.Cout = CB; b.ksize = 3;
         b.stride = 1; b.Ho = Hm; b.Wo = Wm; b.act = act; b.gn_scale = d_sc; b.gn_shift = d_sh; b.res = nullptr; b.out = d_out;
         b.tiles_x = b.tiles_y = b.co_tiles = 0;
+        b.w_wino = d_winoB;
         rc = conv2d_launch(b, st);
     }
     (void)hipStreamSynchronize(st);
@@ -1248,7 +1280,8 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     int cin_pad, cout_pad;
     const int interleave = conv_weight_interleave(Cout, ksize, stride);
     conv_pack_weights(w.data(), Cout, Cin, ksize, interleave, packed, cin_pad, cout_pad);
-    float *d_w, *d_x1, *d_x2 = nullptr, *d_out, *d_res = nullptr, *d_sc, *d_sh, *d_b;
+    float *d_w, *d_x1, *d_x2 = nullptr, *d_out, *d_res = nullptr, *d_sc, *d_sh, *d_b, *d_wino = nullptr;
+    if (int rcw = upload_wino(w.data(), Cout, Cin, ksize, stride, interleave, &d_wino)) return rcw;
     IPDM_HIP_CHECK(hipMalloc((void **)&d_w, packed.size() * 4));
     IPDM_HIP_CHECK(hipMemcpy(d_w, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
     IPDM_HIP_CHECK(hipMalloc((void **)&d_x1, (size_t)B * C1 * H * W * 4));
@@ -1266,7 +1299,7 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     ipdm_randn(d_b, 1, Cout, 6, 0, 0, nullptr);
     ConvArgs a;
     a.x1 = d_x1; a.x2 = d_x2; a.C1 = C1; a.C2 = C2; a.B = B; a.Hs = H; a.Ws = W; a.H = H; a.W = W; a.upsample = 0;
-    a.scale_y = a.scale_x = 1.f; a.w = d_w; a.cout_pad = cout_pad; a.w_interleave = interleave; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
+    a.scale_y = a.scale_x = 1.f; a.w = d_w; a.w_wino = d_wino; a.cout_pad = cout_pad; a.w_interleave = interleave; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
     a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
     a.tiles_x = a.tiles_y = a.co_tiles = 0;
     float *d_split = nullptr;
@@ -1297,6 +1330,7 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
         (void)hipFree(a.dbg_buf);
     }
     (void)hipFree(d_split);
+    (void)hipFree(d_wino);
     (void)hipFree(d_w); (void)hipFree(d_x1); (void)hipFree(d_x2); (void)hipFree(d_out); (void)hipFree(d_res); (void)hipFree(d_sc);
     (void)hipFree(d_sh); (void)hipFree(d_b); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;

@@ -41,6 +41,10 @@ struct ConvArgs {
     // w_up2; when conv_up2_eligible(args) the launcher takes this path and writes `out` PARITY-PLANAR:
     // [n][cout][row & 1][col & 1][Ho/2][Wo/2] (same channel stride as NCHW).  Readers set x1_planar (conv_planar_ok).
     const float *w_up2 = nullptr;
+    // The same layer's weights in the Winograd F(2x2,3x3) domain (conv_pack_weights_wino: U = G g G^T); when
+    // conv_wino_eligible(args) the launcher evaluates the convolution there (conv_wino.hip): 16 instead of 36
+    // multiply-adds per 2x2 outputs, same NCHW output and statistics rows as the direct kernel.
+    const float *w_wino = nullptr;
     int x1_planar = 0;                  // x1 is stored parity-planar (the output of an up2 convolution)
     int up2 = 0;                        // set by the launcher
     int dbg = 0;                        // IPDM_CONV_DBG bit mask (kernel experiments only; 0 on the product path)
@@ -60,7 +64,8 @@ int conv_ws_k_chunk(int ks, int interleave);   // K chunk of the kernel a (ks, w
 
 // per-launch HIP-event timing of kernel classes (bench.py roofline): 0 = conv 3x3 s1 wide tile (the
 // dominant kernel), 1 = every other conv variant, 2 = attention
-constexpr int PROF_CLASSES = 3;
+// 3 = the Winograd-domain form of class 0's layers, recorded with its EXECUTED flops (16/36 of the 3x3 count)
+constexpr int PROF_CLASSES = 4;
 bool prof_enabled();
 void prof_before(int cls, hipStream_t st);
 void prof_after(int cls, double flops, hipStream_t st);
@@ -103,6 +108,11 @@ size_t conv_split_ws_bytes(const ConvArgs &a);     // 0 when conv_split(a) == 1
 constexpr int SPLIT_PIX = 2048;                    // pixels per workgroup (= per statistics row) of the combine pass
 int conv_ws_stats_rows(const ConvArgs &a);
 bool conv_up2_eligible(const ConvArgs &a);         // shape fields + w_up2 + w_interleave decide (dry runs included)
+bool conv_wino_eligible(const ConvArgs &a);        // shape fields + w_wino decide
+bool conv_wino_shape_ok(int Cout, int Cin, int ks, int stride, int interleave);   // worth packing U for this layer
+int conv2d_wino_launch(const ConvArgs &a, hipStream_t st);
+// [Cin/8][Cout/64][xi 16][cout half][k parity][cout 32][k step] = the LDS image of one (chunk, cout tile)
+void conv_pack_weights_wino(const float *w, int Cout, int Cin, std::vector<float> &packed);
 bool conv_ws_planar_ok(const ConvArgs &a);
 bool conv_direct_up2_eligible(const ConvArgs &a);  // narrow Upsample layers: the same parity form inside conv_direct (NCHW output)
 bool conv_planar_ok(const ConvArgs &a);            // the kernel this convolution runs on can read x1 parity-planar
