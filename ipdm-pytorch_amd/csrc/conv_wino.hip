@@ -42,6 +42,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef IPDM_CONV_STAMPS
+#define IPDM_CONV_STAMPS 0          // `make stamps`: in-kernel s_memtime stamps of the phases (a stamped build changes what it measures)
+#endif
+
 namespace {
 
 constexpr int KC = 8;                                  // channels per K chunk (4 MFMA k-steps of 2)
@@ -51,7 +55,9 @@ constexpr int U_FLOATS = 16 * 2 * 2 * 32 * 4;
 constexpr int STAGE = V_FLOATS + U_FLOATS;             // 12288 floats = 48 KB
 constexpr int XCH_FLOATS = 4 * 8 * 64 * 4;             // per consumer wave: 8 x (64 lanes x 16 bytes)
 constexpr int STAT_FLOATS = 4 * 256;
-constexpr size_t LDS_BYTES = (size_t)(2 * STAGE + XCH_FLOATS + STAT_FLOATS) * sizeof(float);
+constexpr int XSCR_FLOATS = 4 * (16 * 36 + 64 * 4);   // the producers' activated windows: per wave 16 row segments of 36 (+ a
+                                                       // dump slot per lane for the 12 of 48 load slots that do not exist)
+constexpr size_t LDS_BYTES = (size_t)(2 * STAGE + XCH_FLOATS + STAT_FLOATS + XSCR_FLOATS) * sizeof(float);
 constexpr int U_CHUNK_FLOATS = U_FLOATS;               // packed weights of one (chunk, cout tile): the U stage image
 
 struct TileId { int n, oy0, ox0, co0; };
@@ -110,133 +116,225 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
 
     if (threadIdx.x >= 256) {
         // =========================================================================== PRODUCERS
-        const int tid = threadIdx.x - 256;
-        const int t = tid & 31, lk = (tid >> 5) & 1;                     // tile, channel parity
-        const int kp = __builtin_amdgcn_readfirstlane(tid >> 6);         // k-step (wave-uniform): channel = 2 kp + lk
-        const int ty = t >> 4, tx = t & 15;
+        // Wave pw stages one tile row (16 tiles: 4 input rows x 34 columns) of FOUR channels of the chunk:
+        //   pw & 1 = tile row, pw >> 1 = channel group.  Per chunk and lane, a three-stage software pipeline:
+        //   G  (beside the consumers' MFMAs)  three 16-byte buffer loads: the wave's 16 row segments of 34 floats, 9 lanes
+        //      per segment; the lane's channel is fixed (lane & 3), so its GroupNorm parameters are two registers.  Wide
+        //      loads: a dword buffer load costs the memory pipeline as much as a 16-byte one (~100 cycles per wave
+        //      instruction beside three other loading waves), and per-thread 4x4 patches fetched as 16 dwords made the
+        //      producers, not the matrix pipe, the bound of the first version (stamps: 2.9k cycles of issue per 2.3k-cycle
+        //      chunk);
+        //   W1 (in the window)  GroupNorm(+SiLU) of those 12 values -> the wave's private LDS scratch X [ch][row][36];
+        //      zero padding re-imposed on border tiles.  Each window element is activated ONCE (the 4x4 patches of
+        //      neighbouring tiles overlap 2.5x);
+        //   R  (beside the MFMAs)  the lane's own 4x4 patch (tile, channel) back from X: 8 ds_read_b64;
+        //   W2 (in the next window)  B^T d B, 16 LDS stores into the stage.
+        // Lane map for R / W2: 16 tiles x 2 k-steps x 2 channel parities, so that the 32 lanes of an LDS store group write
+        // a 64-float span of the [tile][k-step] image at most 2-way conflicted (free).
+        const int tid = threadIdx.x - 256, lane = tid & 63;
+        const int pw = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int tyw = pw & 1, cg = pw >> 1;
+        const int t16 = lane & 15, kpl = (lane >> 4) & 1, lk = lane >> 5;
+        const int t = 16 * tyw + t16, kp = 2 * cg + kpl;               // channel of the chunk = 2 kp + lk = 4 cg + 2 kpl + lk
+        const int q = lane & 3;                                          // G / W1: the lane's channel inside the group
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)a.w, 0, nchunks * a.co_tiles * U_CHUNK_FLOATS * 4, 0x00020000);
-        // Patch offsets of this thread's (tile, channel parity), fixed for a tile.  A producer's VALU instructions outside
-        // the window only get the stall gaps of the partner wave's MFMA stream (~280 cycles each), so interior tiles take
-        // ONE per-lane base plus 16 wave-uniform constants (v_add with a scalar operand); only tiles that touch the image
-        // border pay per-element range checks.  voffp: the same elements of a parity-planar x1 -- the patch origin is odd
-        // in both axes (tile origins are even), so the parity pattern of the 16 elements is fixed too.
-        int voff[16], voffp[PLANAR ? 16 : 1];
-        unsigned okmask = 0xffffu;
-        bool border = false;
-        TileId tl = {0, 0, 0, 0};
-        float *const vdst0 = lds + (lk * 32 + t) * 4 + kp;               // + xi * 256 + stage
-        const int h2 = a.Hs >> 1, w2 = a.Ws >> 1;
-        for (int s = 0; s < S; ++s) {
-            const int k = s / nchunks, ch = s - k * nchunks;
-            if (ch == 0) {
-                tl = decode_tile(a, tile_of(k));
-                const int iy0 = tl.oy0 - 1 + 2 * ty, ix0 = tl.ox0 - 1 + 2 * tx;
-                border = tl.oy0 - 1 < 0 || tl.ox0 - 1 < 0 || tl.oy0 + TH + 1 > a.H || tl.ox0 + TW + 1 > a.W;
-                if (!border) {
-                    const int base = (iy0 * a.Ws + ix0) * 4 + lk * plane_bytes;
+        constexpr int XP = 36;                                           // scratch row pitch (16-byte aligned rows)
+        float *const xw = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + pw * (16 * XP + 256);
+        // slot u = (lane >> 2) + 16 j  ->  (row r, 4-float part) of the lane's channel; 36 of the 48 slots exist
+        int lconst[3], xoff[3];
+        unsigned slot_rp[3];                                             // r | part << 4 | valid << 8 (tile-independent)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) voff[e] = base + ((e >> 2) * a.Ws + (e & 3)) * 4;
-                    if (PLANAR) {
-                        const int basep = (((iy0 - 1) >> 1) * w2 + ((ix0 - 1) >> 1)) * 4 + lk * plane_bytes;
+        for (int j = 0; j < 3; ++j) {
+            const int u = (lane >> 2) + 16 * j, r = u / 9, part = u - r * 9;
+            const bool v = u < 36;
+            // (the last part holds window columns 32, 33 and two floats past the window: the next pixels of the row, the
+            //  next row, or -- at the very end of the tensor -- dwords past num_records, which a raw buffer load range-checks
+            //  one by one and returns as 0 (tools/ubench/oob_probe.hip); they land in the scratch rows' padding)
+            lconst[j] = v ? (r * a.Ws + 4 * part) * 4 + q * plane_bytes : OOB;
+            xoff[j] = v ? (q * 4 + r) * XP + 4 * part : 16 * XP + lane * 4;      // (slots that do not exist: the lane's dump slot)
+            slot_rp[j] = (unsigned)r | (unsigned)part << 4 | (v ? 256u : 0u);
+        }
+        // per-lane LDS bases of both stages, so that every store below is base + a 16-bit immediate (no per-store VALU)
+        float *const wdstP[2] = {lds + V_FLOATS + tid * 4, lds + STAGE + V_FLOATS + tid * 4};              // + e * 1024
+        // tile descriptors: issue side (G) and activation side (W1, one or two chunks behind)
+        int g_base = 0, g_n = 0, g_co = 0;                              // byte offset of the wave's window origin, sample, cout tile
+        const float *g_src1 = a.x1, *g_src2 = a.x2 ? a.x2 : a.x1;      // the sample's planes in the two sources
+        int w_co = 0;                                                    // cout tile of the weights being issued (one step behind G)
+        bool g_bord = false;
+        int vo[3] = {lconst[0], lconst[1], lconst[2]};                   // per-lane load offsets of the tile being loaded
+        int g_so = 0;                                                    // ... and the scalar part of its window origin
+        unsigned g_vm = 0xfffu, g_lsh = 0;                              // validity of the 12 loaded elements; left-edge shift
+        unsigned a_vm = 0xfffu, a_lsh = 0;
+        bool a_bord = false;
+        auto describe = [&](int k) __attribute__((always_inline)) {
+            const TileId tl = decode_tile(a, tile_of(k));
+            const int iy0 = tl.oy0 - 1 + 2 * tyw, ix0 = tl.ox0 - 1;
+            g_n = tl.n; g_co = tl.co0 / BN;
+            g_src1 = a.x1 + (size_t)tl.n * a.C1 * (plane_bytes / 4);
+            g_src2 = a.x2 ? a.x2 + (size_t)tl.n * a.C2 * (plane_bytes / 4) : g_src1;
+            g_bord = tl.oy0 - 1 < 0 || tl.ox0 - 1 < 0 || tl.oy0 + TH + 1 > a.H || tl.ox0 + TW + 1 > a.W;
+            g_base = (iy0 * a.Ws + ix0) * 4;
+            g_so = g_bord ? 0 : g_base;
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int dy = e >> 2, dx = e & 3;      // element parity = (1 + d) & 1, plane index offset = (d + 1) >> 1
-                            voffp[PLANAR ? e : 0] = basep + (((((1 + dy) & 1) * 2 + ((1 + dx) & 1)) * h2 + ((dy + 1) >> 1)) * w2 + ((dx + 1) >> 1)) * 4;
-                        }
+            for (int j = 0; j < 3; ++j) vo[j] = lconst[j];
+            if (g_bord) {
+                g_vm = 0; g_lsh = 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int r = slot_rp[j] & 15, part = slot_rp[j] >> 4 & 15;
+                    const bool rowok = (slot_rp[j] & 256u) && iy0 + r >= 0 && iy0 + r < a.H;
+                    // the 16 bytes of the leftmost part of an image row start one pixel before the row: shifted by one
+                    // pixel and rotated back after the load (at the very first row they would start before the buffer)
+                    const bool lsh = rowok && ix0 + 4 * part < 0;
+                    g_lsh |= lsh ? 1u << j : 0u;
+                    vo[j] = rowok ? lconst[j] + g_base + (lsh ? 4 : 0) : OOB;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ix = ix0 + 4 * part + e;
+                        g_vm |= (rowok && ix >= 0 && ix < a.W && 4 * part + e < 34) ? 1u << (4 * j + e) : 0u;
                     }
-                    okmask = 0xffffu;
-                } else {
-                    okmask = 0;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int iy = iy0 + (e >> 2), ix = ix0 + (e & 3);
-                        const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                        okmask |= ok ? 1u << e : 0u;
-                        voff[e] = ok ? (iy * a.Ws + ix) * 4 + lk * plane_bytes : OOB;
-                        if (PLANAR) voffp[PLANAR ? e : 0] = ok ? ((((iy & 1) * 2 + (ix & 1)) * h2 + (iy >> 1)) * w2 + (ix >> 1)) * 4 + lk * plane_bytes : OOB;
-                    }
+                    // (a load of a border tile may straddle the end of an image row: the next row's pixels, or -- at the last
+                    //  row of the tensor -- dwords past num_records, which a raw buffer load range-checks one by one and
+                    //  returns as 0: tools/ubench/oob_probe.hip; either way those elements are masked by g_vm)
                 }
             }
-            const int c0 = ch * KC;
-            float *const stage = lds + (s & 1) * STAGE;
-            const bool from1 = c0 < a.C1;
-            const int csrc = from1 ? a.C1 : a.C2;
-            const float *src = from1 ? a.x1 + (size_t)tl.n * a.C1 * (plane_bytes / 4) : a.x2 + (size_t)tl.n * a.C2 * (plane_bytes / 4);
-            const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, csrc * plane_bytes, 0x00020000);
-            const int cs0 = (from1 ? c0 : c0 - a.C1) + 2 * kp;               // (+ lk through the per-lane offset)
-            // weights first (no transform: to LDS as soon as they land), then the raw patch
-            f32x4 w_reg[8];
-            const int w_soff = (ch * a.co_tiles + tl.co0 / BN) * (U_CHUNK_FLOATS * 4);
+        };
+        struct Raw { f32x4 v[3]; float sc, sh; };
+        Raw rawA, rawB;
+        f32x4 wA[8], wB[8];
+        // (no integer division, 64-bit address arithmetic or per-step address VALU outside the window: beside the partner's
+        //  MFMA stream every VALU instruction of this wave waits for a stall gap -- the first pipelined version spent 2.6k
+        //  cycles per 2.3k-cycle chunk in its "issue" phase on three uniform s / nchunks divisions and two 64-bit addresses)
+        const __amdgpu_buffer_rsrc_t gsc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.act ? a.gn_scale : a.out), 0, a.act ? (a.B * Ctot + 64) * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t gsh_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.act ? a.gn_shift : a.out), 0, a.act ? (a.B * Ctot + 64) * 4 : 0, 0x00020000);
+        // Every step issues the SAME 13 loads, needed or not: past the end of the stream they re-read chunks of the last
+        // tile (valid addresses, results unused; without a GroupNorm prologue the two parameter loads go through a
+        // descriptor with zero records and are dropped by the range check, still counted by vmcnt).  With conditional issue the compiler's
+        // waitcnt pass has to assume the shortest path and made the LDS stores of w(s) wait for vmcnt(0) -- i.e. for the
+        // loads this very step had just issued: no prefetch at all (2.8k cycles of "issue" per 2.3k-cycle chunk).
+        auto issue_w = [&](int ch, f32x4 (&w)[8]) __attribute__((always_inline)) {
+            if (ch == 0) w_co = g_co;                                    // the weights enter the tile described last
+            const int w_soff = (ch * a.co_tiles + w_co) * (U_CHUNK_FLOATS * 4);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                w_reg[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (tid + e * 256) * 16, w_soff, 0));
-            float d[16];
-            if (PLANAR && from1) {       // (uniform branch) only x1 is stored parity-planar; the skip half of a concat is NCHW
+                w[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (tid + e * 256) * 16, w_soff, 0));
+        };
+        auto issue_raw = [&](int ch, Raw &r) __attribute__((always_inline)) {
+            const int c0 = ch * KC;
+            const bool from1 = c0 < a.C1;
+            const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(from1 ? g_src1 : g_src2), 0, (from1 ? a.C1 : a.C2) * plane_bytes, 0x00020000);
+            // interior tiles: tile origin through the scalar offset (g_so), per-lane offsets fixed for the kernel; border
+            // tiles: range-checked per-lane offsets; describe() put whichever applies into vo[]
+            const int so = ((from1 ? c0 : c0 - a.C1) + 4 * cg) * plane_bytes + g_so;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) d[e] = bload(x_rsrc, voffp[PLANAR ? e : 0], cs0 * plane_bytes);
-            } else {
+            for (int j = 0; j < 3; ++j)
+                r.v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo[j], so, 0));
+            const int gso = (g_n * Ctot + c0 + 4 * cg) * 4;
+            r.sc = bload(gsc_rsrc, q * 4, gso);
+            r.sh = bload(gsh_rsrc, q * 4, gso);
+        };
+        // W1: activate the 12 landed values, zero what lies outside the image, park them in the wave's scratch
+        auto activate = [&](Raw &r) __attribute__((always_inline)) {
+            // pairs: the four non-transcendental operations of an element are packed-f32 instructions (the window's cost
+            // is its instruction count: ~10 cycles per instruction of a lone wave, stamps)
+            f32x2 d[6];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) d[e] = bload(x_rsrc, voff[e], cs0 * plane_bytes);
+            for (int j = 0; j < 3; ++j) { d[2 * j] = f32x2{r.v[j][0], r.v[j][1]}; d[2 * j + 1] = f32x2{r.v[j][2], r.v[j][3]}; }
+            if (a_bord) {        // (uniform) undo the left-edge shift: {x0, x1, x2, x3} loaded from one pixel further right
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (a_lsh >> j & 1) { d[2 * j + 1] = f32x2{d[2 * j][1], d[2 * j + 1][0]}; d[2 * j] = f32x2{0.0f, d[2 * j][0]}; }
             }
-            float sc = 1.0f, sh = 0.0f;
             if (a.act) {
-                sc = a.gn_scale[(size_t)tl.n * Ctot + c0 + 2 * kp + lk];
-                sh = a.gn_shift[(size_t)tl.n * Ctot + c0 + 2 * kp + lk];
+                const f32x2 sc2 = {r.sc, r.sc}, sh2 = {r.sh, r.sh};
+#pragma unroll
+                for (int e = 0; e < 6; ++e) d[e] = __builtin_elementwise_fma(d[e], sc2, sh2);
+                if (a.act == 2) {
+                    f32x2 ex[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) ex[e] = d[e] * -1.4426950408889634f;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) { ex[e][0] = __builtin_amdgcn_exp2f(ex[e][0]); ex[e][1] = __builtin_amdgcn_exp2f(ex[e][1]); }
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) ex[e] = ex[e] + 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) { ex[e][0] = __builtin_amdgcn_rcpf(ex[e][0]); ex[e][1] = __builtin_amdgcn_rcpf(ex[e][1]); }
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) d[e] = d[e] * ex[e];
+                }
             }
+            if (a_bord) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) d[e >> 1][e & 1] = (a_vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                *reinterpret_cast<f32x4 *>(xw + xoff[j]) = f32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
+        };
+        const bool pstamp = IPDM_CONV_STAMPS && (a.dbg & 8) != 0;
+        unsigned long long p_issue = 0, p_wait = 0, p_math = 0, p_hand = 0, p_t = 0;
+        // one step: on entry  w(s) is in `wc` (issued one step ago), raw(s+1) in `rc` (issued one step ago), patch(s) in
+        // registers; the step issues w(s+1) -> `wn` and raw(s+2) -> `rn`
+        int k = 0, ch = 0;                                         // tile / chunk-in-tile of the step's chunk s (running counters)
+        auto step = [&](int s, auto par, f32x4 (&wc)[8], f32x4 (&wn)[8], Raw &rc, Raw &rn) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par)::value;                // s & 1: the stage addresses are compile-time constants
+            if (pstamp) p_t = __builtin_amdgcn_s_memtime();
+            const bool more1 = s + 1 < S, more2 = s + 2 < S;
+            const int ch1 = ch + 1 == nchunks ? 0 : ch + 1, ch2 = ch1 + 1 == nchunks ? 0 : ch1 + 1;
+            issue_w(ch1, wn);
+            issue_raw(ch2, rn);
+            // w(s), raw(s+1) have landed; this step's own 13 loads stay in flight across the window
+            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
             // stage (s&1) was last read by chunk s-2, which the consumers finished before the previous hand-over
 #pragma unroll
-            for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x4 *>(stage + V_FLOATS + (tid + e * 256) * 4) = w_reg[e];
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x4 *>(wdstP[PAR] + e * 1024) = wc[e];
+            if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_issue += now - p_t; p_t = now; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // E (the consumers' exchange barrier of the tile that just ended) already says "the matrix pipe is idle": the
             // window of a tile's first chunk then overlaps the consumers' store epilogue instead of following it
             const bool after_tile = ch == 0 && s > 0;
-            if (after_tile) __syncthreads();               // E
-            else __syncthreads();                          // A: consumers have finished chunk s-1
-            // ---- the VALU window: GroupNorm(+SiLU), zero padding re-imposed, B^T d B, 16 LDS stores
-            if (a.act) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) d[e] = fmaf(d[e], sc, sh);
-                if (a.act == 2) {
-                    float ex[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) ex[e] = d[e] * -1.4426950408889634f;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) ex[e] = __builtin_amdgcn_exp2f(ex[e]);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) ex[e] = ex[e] + 1.0f;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) ex[e] = __builtin_amdgcn_rcpf(ex[e]);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) d[e] = d[e] * ex[e];
-                }
-                if (border) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) d[e] = (okmask >> e & 1) ? d[e] : 0.0f;
-                }
+            __builtin_amdgcn_sched_barrier(0);             // (the scheduler may not lift the window's register-only VALU above
+            __syncthreads();                               //  the barrier) E (after a tile) or A: consumers have finished chunk s-1
+            __builtin_amdgcn_sched_barrier(0);
+            if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_wait += now - p_t; p_t = now; }
+            // ---- the VALU window (the consumers run W2(s) beside it)
+            if (more1) {                                       // W1(s+1)
+                if (ch == nchunks - 1) { a_vm = g_vm; a_lsh = g_lsh; a_bord = g_bord; }      // chunk s+1 opens the tile described last
+                activate(rc);
             }
-            {
-                float tt[16];      // B^T d: rows of the patch combined
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    tt[0 + x] = d[0 + x] - d[8 + x];
-                    tt[4 + x] = d[4 + x] + d[8 + x];
-                    tt[8 + x] = d[8 + x] - d[4 + x];
-                    tt[12 + x] = d[4 + x] - d[12 + x];
-                }
-                float *vdst = vdst0 + (s & 1) * STAGE;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {                 // (B^T d) B: columns combined
-                    vdst[(i * 4 + 0) * 256] = tt[i * 4 + 0] - tt[i * 4 + 2];
-                    vdst[(i * 4 + 1) * 256] = tt[i * 4 + 1] + tt[i * 4 + 2];
-                    vdst[(i * 4 + 2) * 256] = tt[i * 4 + 2] - tt[i * 4 + 1];
-                    vdst[(i * 4 + 3) * 256] = tt[i * 4 + 1] - tt[i * 4 + 3];
-                }
-            }
+            // the next tile's descriptors, while the SIMD is still ours (its first raw loads are issued two steps from now)
+            if (ch == nchunks - 3 && k + 1 < n_my) describe(k + 1);
+            if (pstamp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                          const unsigned long long now = __builtin_amdgcn_s_memtime(); p_math += now - p_t; p_t = now; }
+            __builtin_amdgcn_sched_barrier(0);
             if (after_tile) __syncthreads();               // A (the consumers arrive after their stores)
             __syncthreads();                               // hand-over: stage (s&1) is complete
+            __builtin_amdgcn_sched_barrier(0);
+            ch = ch1;
+            k += ch1 == 0 ? 1 : 0;
+            if (pstamp) p_hand += __builtin_amdgcn_s_memtime() - p_t;
+        };
+        if (S > 0) {
+            // prologue (nobody multiplies yet: the SIMDs are free): tile 0, G(0), G(1), W1(0), R(0)
+            describe(0);
+            a_vm = g_vm; a_lsh = g_lsh; a_bord = g_bord;
+            issue_w(0, wA);
+            issue_raw(0, rawB);
+            issue_raw(1, rawA);                                // (nchunks >= 4: chunk 1 belongs to tile 0)
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            activate(rawB);
+            __syncthreads();                                   // P: X(0) is in the scratch; the consumers fetch their patches
+            for (int s = 0; s < S; s += 2) {
+                step(s, std::integral_constant<int, 0>{}, wA, wB, rawA, rawB);
+                if (s + 1 < S) step(s + 1, std::integral_constant<int, 1>{}, wB, wA, rawB, rawA);
+            }
+            __syncthreads();                               // E of the last tile
         }
-        if (S > 0) __syncthreads();                        // E of the last tile
+        if (pstamp && !(a.dbg & 16) && tid == 0) {
+            unsigned long long *dd = a.dbg_buf + (size_t)blockIdx.x * 8 + 4;
+            dd[0] = p_issue; dd[1] = p_wait; dd[2] = p_math; dd[3] = p_hand;
+        }
         return;
     }
 
@@ -257,12 +355,62 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         nb = bload(b_rsrc, lk ? OOB : l31 * 4, (t.co0 + h * 32) * 4);
     };
     if (S > 0 && ih == 0) fetch_bias(0);
+    // R / W2 (the consumers' share of the window): wave w transforms the (tile, channel) pairs of producer wave w's
+    // scratch -- lane map 16 tiles x 2 k-steps x 2 channel parities, so that the 32 lanes of an LDS store group write a
+    // 64-float span of the [tile][k-step] image at most 2-way conflicted (free)
+    const int w_t16 = lane & 15, w_kpl = (lane >> 4) & 1;
+    const float *const xr = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + swave * (16 * 36 + 256) + ((2 * w_kpl + lk) * 4) * 36 + 2 * w_t16;
+    const int v_lane = (lk * 32 + 16 * (swave & 1) + w_t16) * 4 + 2 * (swave >> 1) + w_kpl;      // + xi * 256 (+ stage)
+    float patch[16];
+    auto read_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x2 lo = *reinterpret_cast<const f32x2 *>(xr + r * 36), hi = *reinterpret_cast<const f32x2 *>(xr + r * 36 + 2);
+            patch[4 * r] = lo[0]; patch[4 * r + 1] = lo[1]; patch[4 * r + 2] = hi[0]; patch[4 * r + 3] = hi[1];
+        }
+    };
     const int a_off = V_FLOATS + ((((8 * ih) * 2 + h) * 2 + lk) * 32 + l31) * 4;      // + e * 512 floats
     const int b_off = (((8 * ih) * 2 + lk) * 32 + l31) * 4;                           // + e * 256 floats
+    const bool stamp = IPDM_CONV_STAMPS && (a.dbg & 8) != 0;
+    const bool estamp = IPDM_CONV_STAMPS && (a.dbg & 16) != 0;      // epilogue split into the producers' four slots
+    unsigned long long e_p1 = 0, e_wait = 0, e_p2 = 0, e_p3 = 0, e_t = 0;
+    unsigned long long t_mma = 0, t_epi = 0, t_bar = 0;
+    const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long t_last = t_begin;
+    int k = 0, ch = -1;                                    // running (tile, chunk in tile): no division in the MFMA wave
+    if (S > 0) {
+        __syncthreads();                                   // P: the producers' prologue has put X(0) into the scratch
+        read_patch();                                      // (window 0 overwrites it with X(1): read before barrier A_0)
+    }
     for (int s = 0; s < S; ++s) {
-        const int k = s / nchunks, ch = s - k * nchunks;
-        __syncthreads();                                   // A: chunk s-1 done -> the producers' burst may use the SIMD
+        if (++ch == nchunks) { ch = 0; ++k; }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                   // A: chunk s-1 done -> the SIMD is free for the window
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // W2(s): B^T d B of the lane's 4x4 patch (read from the producers' scratch one chunk ago, beside the MFMAs)
+            float tt[16];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                tt[0 + x] = patch[0 + x] - patch[8 + x];
+                tt[4 + x] = patch[4 + x] + patch[8 + x];
+                tt[8 + x] = patch[8 + x] - patch[4 + x];
+                tt[12 + x] = patch[4 + x] - patch[12 + x];
+            }
+            float *vdst = lds + (s & 1) * STAGE + v_lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vdst[(i * 4 + 0) * 256] = tt[i * 4 + 0] - tt[i * 4 + 2];
+                vdst[(i * 4 + 1) * 256] = tt[i * 4 + 1] + tt[i * 4 + 2];
+                vdst[(i * 4 + 2) * 256] = tt[i * 4 + 2] - tt[i * 4 + 1];
+                vdst[(i * 4 + 3) * 256] = tt[i * 4 + 1] - tt[i * 4 + 3];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                   // hand-over: stage (s&1) is complete
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < S) read_patch();                       // R(s+1): written in this window, used in the next one
+        if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_bar += now - t_last; t_last = now; }
         if (ch == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -285,8 +433,10 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
                 if (e + 1 < 8) { a_c = a_n; b_c = b_n; }
             }
         }
+        if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_mma += now - t_last; t_last = now; }
         if (ch != nchunks - 1) continue;
         // ---------------------------------------------------------------- tile epilogue
+        if (estamp) e_t = __builtin_amdgcn_s_memtime();
         // + bias through position (1, 1) (accumulator 5 of the ih = 0 waves), whose output coefficients are all 1
         if (ih == 0) {
             acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb, 1.0f, acc[5], 0, 0, 0);
@@ -316,62 +466,81 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
                 *reinterpret_cast<f32x4 *>(xw + (r >> 1) * 256) = snd;
             }
         }
+        if (estamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); e_p1 += now - e_t; e_t = now; }
         __syncthreads();                                   // E: both halves of every (tile, cout) are in LDS
+        if (estamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); e_wait += now - e_t; e_t = now; }
         const size_t sample = (size_t)t.n * a.Cout * out_plane;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * out_plane * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0, a.Cout * out_plane * 4, 0x00020000);
-        const int py = t.oy0 + 2 * ty + ih, px = t.ox0 + 2 * tx;
+        // Two neighbouring lanes (tile columns 2m, 2m + 1) hold 4 consecutive pixels of the row between them.  Registers are
+        // taken in pairs (couts c, c + 1): the lanes swap one half each (DPP quad_perm [1,0,3,2]), after which the even lane
+        // owns the 4 pixels of cout c and the odd lane those of cout c + 1 -- 16-byte stores and residual loads, half as
+        // many memory instructions (the store path retires about one instruction per 100 cycles and wave whatever its width:
+        // with 8-byte stores this phase took 5.3k cycles per tile without residual, 11.7k with residual and statistics), and
+        // the statistics need 3 DPP steps per pair instead of 4 per register.
+        const int odd = tx & 1;
+        const int py = t.oy0 + 2 * ty + ih, px4 = t.ox0 + 4 * (tx >> 1);
         const bool rok = py < a.Ho;
-        const int voff2 = (rok && px + 1 < a.Wo) ? lane_off : OOB;               // both pixels of the lane's run
-        const bool ragged = t.ox0 + TW > a.Wo && (a.Wo & 1) != 0;                // (wave-uniform) a run straddles the right edge
-        const int voff1 = (ragged && rok && px + 1 == a.Wo) ? lane_off : OOB;    // ... then only its first pixel exists
+        const int lane_off4 = ((lk * 4 + odd) * out_plane + (2 * ty + ih) * a.Wo + 4 * (tx >> 1)) * 4;
+        const int voff4 = (rok && px4 + 3 < a.Wo) ? lane_off4 : OOB;             // all four pixels of the lane's run
+        const bool ragged = t.ox0 + TW > a.Wo && (a.Wo & 3) != 0;                // (wave-uniform) a run straddles the right edge
+        const int nval = a.Wo - px4;                                              // ... then it has 1..3 pixels
+        const bool part = ragged && rok && nval > 0 && nval < 4;
         const int so0 = ((t.co0 + h * 32) * out_plane + min(t.oy0, a.Ho - 1) * a.Wo + t.ox0) * 4;
-        const float *xr = xch + ((swave ^ 1) * 8) * 256 + lane * 4;
+        const float *xr2 = xch + ((swave ^ 1) * 8) * 256 + lane * 4;
         float *sb = stat_lds + swave * 256;
-        f32x2 rv[2][4];
-        float rv1[2][4];
-        auto load_res = [&](int g, f32x2 (&dst)[4], float (&dst1)[4]) __attribute__((always_inline)) {
-            // registers 4 g .. 4 g + 3 are couts 8 g + {0..3} (+ 4 lk in lane_off)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int so = so0 + (8 * g + u) * plane4;
-                dst[u] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, voff2, so, 0));
-                if (ragged) dst1[u] = bload(r_rsrc, voff1, so);
-            }
+#define IPDM_SWAP1(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0xB1, 0xf, 0xf, false))
+#define IPDM_ROR(v, c) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (c), 0xf, 0xf, false))
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        f32x4 rv[2];
+        auto load_res = [&](int i, f32x4 &dst) __attribute__((always_inline)) {      // pair i: registers 2 i, 2 i + 1
+            const int so = so0 + (8 * (i >> 1) + 2 * (i & 1)) * plane4;
+            dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4, so, 0));
         };
-        if (a.res) load_res(0, rv[0], rv1[0]);
+        if (a.res) load_res(0, rv[0]);
+        f32x4 got = {0, 0, 0, 0};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (a.res && g + 1 < 4) load_res(g + 1, rv[(g + 1) & 1], rv1[(g + 1) & 1]);
-            const f32x4 got0 = *reinterpret_cast<const f32x4 *>(xr + (2 * g) * 256);
-            const f32x4 got1 = *reinterpret_cast<const f32x4 *>(xr + (2 * g + 1) * 256);
+        for (int i = 0; i < 8; ++i) {
+            const int g = i >> 1, u = 2 * (i & 1), r = 4 * g + u;
+            if (a.res && i + 1 < 8) load_res(i + 1, rv[(i + 1) & 1]);
+            got = *reinterpret_cast<const f32x4 *>(xr2 + i * 256);                     // partner's {T(r)[0], T(r)[1], T(r+1)[0], T(r+1)[1]}
+            // output row 0 = (T0 + T1) + T2;  output row 1 = T1 - (T2 + T3)
+            const float ya0 = ih == 0 ? keep[r][0] + got[0] : got[0] - keep[r][0], ya1 = ih == 0 ? keep[r][1] + got[1] : got[1] - keep[r][1];
+            const float yb0 = ih == 0 ? keep[r + 1][0] + got[2] : got[2] - keep[r + 1][0], yb1 = ih == 0 ? keep[r + 1][1] + got[3] : got[3] - keep[r + 1][1];
+            // (scalars on purpose: with the halves as 2-vectors and vector selects the compiler folded the two DPP moves
+            //  into one and every lane received the first component twice)
+            const float give0 = odd ? ya0 : yb0, give1 = odd ? ya1 : yb1;
+            const float recv0 = IPDM_SWAP1(give0), recv1 = IPDM_SWAP1(give1);
+            f32x4 v;
+            v[0] = odd ? recv0 : ya0; v[1] = odd ? recv1 : ya1; v[2] = odd ? yb0 : recv0; v[3] = odd ? yb1 : recv1;
+            const int so = so0 + (8 * g + u) * plane4;
+            if (a.res) v += rv[i & 1];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4, so, 0);
+            if (ragged) {            // (wave-uniform) the run that straddles the edge: element by element, by its lane
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = 4 * g + u;
-                const float p0 = u < 2 ? got0[2 * u] : got1[2 * (u - 2)], p1 = u < 2 ? got0[2 * u + 1] : got1[2 * (u - 2) + 1];
-                // output row 0 = (T0 + T1) + T2;  output row 1 = T1 - (T2 + T3)
-                f32x2 y = ih == 0 ? f32x2{keep[r][0] + p0, keep[r][1] + p1} : f32x2{p0 - keep[r][0], p1 - keep[r][1]};
-                const int so = so0 + (8 * g + u) * plane4;
-                if (a.res) y += rv[g & 1][u];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), o_rsrc, voff2, so, 0);
-                float y0 = y[0];
-                if (ragged) {
-                    y0 = ih == 0 ? keep[r][0] + p0 : p0 - keep[r][0];
-                    if (a.res) y0 += rv1[g & 1][u];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0), o_rsrc, voff1, so, 0);
+                for (int e = 0; e < 4; ++e) {
+                    const int vo1 = (part && e < nval) ? lane_off4 + 4 * e : OOB;
+                    float x = v[e];
+                    if (a.res) x += bload(r_rsrc, vo1, so);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), o_rsrc, vo1, so, 0);
+                    if (part) v[e] = e < nval ? x : 0.0f;
                 }
-                if (a.stats) {
-                    // fused GroupNorm statistics of the output: one row of per-cout {sum, sum of squares} per PIXEL ROW and
-                    // 32-pixel column block, as conv_ws.hip writes them; the 16 lanes of a DPP row share (pixel row, cout)
-                    const bool ok2 = voff2 != OOB, ok1 = ragged && voff1 != OOB;
-                    float s1 = ok2 ? y[0] + y[1] : (ok1 ? y0 : 0.0f);
-                    float s2 = ok2 ? fmaf(y[1], y[1], y[0] * y[0]) : (ok1 ? y0 * y0 : 0.0f);
-                    s1 = sum_row16(s1);
-                    s2 = sum_row16(s2);
-                    if (tx == 0) *reinterpret_cast<f32x2 *>(sb + (ty * 32 + 8 * g + u + 4 * lk) * 2) = f32x2{s1, s2};
-                }
+            }
+            if (a.stats) {
+                // fused GroupNorm statistics of the output: one row of per-cout {sum, sum of squares} per PIXEL ROW and
+                // 32-pixel column block, as conv_ws.hip writes them; the 8 lanes of one parity in a DPP row share a cout
+                const bool ok = voff4 != OOB || part;
+                float s1 = ok ? (v[0] + v[1]) + (v[2] + v[3]) : 0.0f;
+                float s2 = ok ? fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0]))) : 0.0f;
+                s1 += IPDM_ROR(s1, 0x122); s2 += IPDM_ROR(s2, 0x122);              // row_ror:2, 4, 8: lanes of the same parity
+                s1 += IPDM_ROR(s1, 0x124); s2 += IPDM_ROR(s2, 0x124);
+                s1 += IPDM_ROR(s1, 0x128); s2 += IPDM_ROR(s2, 0x128);
+                if (tx < 2) *reinterpret_cast<f32x2 *>(sb + (ty * 32 + 8 * g + u + tx + 4 * lk) * 2) = f32x2{s1, s2};
             }
         }
+#undef IPDM_SWAP1
+#undef IPDM_ROR
+        if (estamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); e_p2 += now - e_t; e_t = now; }
         if (a.stats) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -382,6 +551,16 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if (estamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long now = __builtin_amdgcn_s_memtime(); e_p3 += now - e_t; }
+        if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_epi += now - t_last; t_last = now; }
+    }
+    if (estamp && tid == 0) {
+        unsigned long long *d = a.dbg_buf + (size_t)blockIdx.x * 8 + 4;
+        d[0] = e_p1; d[1] = e_wait; d[2] = e_p2; d[3] = e_p3;
+    }
+    if (stamp && tid == 0) {
+        unsigned long long *d = a.dbg_buf + (size_t)blockIdx.x * 8;
+        d[0] = t_mma; d[1] = t_epi; d[2] = t_bar; d[3] = __builtin_amdgcn_s_memtime() - t_begin;
     }
 }
 
@@ -399,7 +578,7 @@ bool conv_wino_eligible(const ConvArgs &a)
     if (a.w_interleave != 2 && a.w_interleave != 4) return false;
     const int Ctot = a.C1 + a.C2;
     if (a.Cout % BN || Ctot % KC || Ctot < 32 || (a.C2 && a.C1 % KC)) return false;
-    if ((a.x1_planar && ((a.Hs | a.Ws) & 1)) || conv_up2_eligible(a)) return false;
+    if (a.x1_planar || conv_up2_eligible(a)) return false;      // (parity-planar inputs stay on the direct kernel)
     return conv_ws_split(a) == 1;
 }
 
@@ -438,6 +617,7 @@ int conv2d_wino_launch(const ConvArgs &args, hipStream_t st)
     a.tiles_y = cdiv(a.Ho, TH);
     a.co_tiles = a.Cout / BN;
     a.ksplit = 1;
+    a.dbg = a.dbg_buf ? (opt(OPT_CONV_DBG) & 24) : 0;
     IPDM_REQUIRE(conv_wino_eligible(args), "conv2d_wino: layer not eligible");
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29) &&
                      (long)a.Cout * a.Ho * a.Wo < (1L << 29) && (long)(a.C1 + a.C2) / KC * a.co_tiles * U_CHUNK_FLOATS < (1L << 29),

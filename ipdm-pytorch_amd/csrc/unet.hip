@@ -1306,7 +1306,7 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     if (conv_split_ws_bytes(a)) IPDM_HIP_CHECK(hipMalloc((void **)&d_split, conv_split_ws_bytes(a)));
     a.split_ws = d_split;
     int rc = 0;
-    const bool stamps = (opt(OPT_CONV_DBG) & 8) != 0;
+    const bool stamps = (opt(OPT_CONV_DBG) & 24) != 0;
     if (stamps) { IPDM_HIP_CHECK(hipMalloc((void **)&a.dbg_buf, 4096 * 8 * 8)); IPDM_HIP_CHECK(hipMemset(a.dbg_buf, 0, 4096 * 8 * 8)); }
     for (int i = 0; i < 3 && !rc; ++i) rc = conv2d_launch(a, nullptr);
     hipEvent_t e0, e1;

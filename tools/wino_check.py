@@ -39,13 +39,14 @@ def run(B, C1, C2, H, W, Cout, act, res, seed=1):
     w64 = ref(torch.float64)
     w32 = ref(torch.float32)
     outs = {}
+    x1d, x2d, rd = x1.to(DEV), (x2.to(DEV) if C2 else None), (r.to(DEV) if res else None)      # (kept alive across the calls)
+    wn, bn, gn_, ben = (np.ascontiguousarray(t.numpy()) for t in (w, bias, gamma, beta))
     for mode in (0, 1):
         out = torch.full((B, Cout, H, W), float("nan"), device=DEV)
         with _lib.option("conv_no_wino", mode):
-            _lib.call("ipdm_op_conv2d", _lib.ptr(x1.to(DEV)), C1, _lib.ptr(x2.to(DEV)) if C2 else None, C2, B, H, W, H, W,
-                      _lib.ptr(np.ascontiguousarray(w.numpy())), _lib.ptr(np.ascontiguousarray(bias.numpy())), Cout, 3, 1, act, groups,
-                      _lib.ptr(np.ascontiguousarray(gamma.numpy())), _lib.ptr(np.ascontiguousarray(beta.numpy())),
-                      _lib.ptr(r.to(DEV)) if res else None, _lib.ptr(out), _lib.current_stream())
+            _lib.call("ipdm_op_conv2d", _lib.ptr(x1d), C1, _lib.ptr(x2d), C2, B, H, W, H, W, _lib.ptr(wn), _lib.ptr(bn), Cout, 3, 1,
+                      act, groups, _lib.ptr(gn_), _lib.ptr(ben), _lib.ptr(rd), _lib.ptr(out), _lib.current_stream())
+        torch.cuda.synchronize()
         outs[mode] = out.cpu()
 
     def d(a):
@@ -84,6 +85,20 @@ def main():
     run(2, 128, 0, 64, 64, 128, 2, True)
     run(1, 256, 0, 32, 57, 256, 1, False)        # K-split shape stays direct (few tiles): both rows equal
     run(1, 64, 0, 130, 250, 128, 2, True)
+    run(1, 128, 0, 96, 64, 64, 2, True)
+    run(2, 64, 64, 70, 131, 64, 1, True)         # concat, odd width
+    run(1, 64, 0, 64, 96, 64, 0, False)
+    run(1, 64, 0, 76, 65, 64, 2, False)          # ox0 + 33 == W: the last part of an interior tile ends with the row
+    run(1, 64, 0, 75, 40, 64, 2, True)           # right-edge parts straddle the row end; odd height
+    run(1, 64, 0, 33, 97, 64, 0, False)
+    run(3, 64, 0, 50, 70, 128, 1, False)
+    run(2, 32, 0, 61, 129, 64, 2, True)          # 4 chunks (the minimum), odd x odd
+    if os.environ.get("IPDM_LIB_PATH"):          # stamps build: phase cycles of two shapes
+        with _lib.option("conv_dbg", int(os.environ.get("WINO_DBG", "8"))):
+            bench(8, 128, 0, 512, 512, 128, 2, True, iters=3)
+            bench(8, 128, 0, 512, 512, 128, 0, False, iters=3)
+            bench(8, 64, 0, 512, 512, 64, 2, True, iters=3)
+        return
     bench(8, 128, 0, 512, 512, 128, 2, True)
     if quick:
         return
