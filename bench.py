@@ -22,13 +22,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak (= f32 vector peak)
+PEAK_HBM_GBS = 8000.0             # same guide: HBM3E peak (6.3 TB/s achievable by a streaming copy)
 PEAK_BF16_MFMA_TFLOPS = 2516.8    # same table: the dense bf16 MFMA rate is 16x the f32 one
 
 
-def kernel_source_sha16():
+def kernel_source_sha16(fname="conv_wino.hip"):
     """Identity of the build the counters were taken on: sha256 of the dominant kernel's source file."""
     import hashlib
-    with open(os.path.join(ROOT, "ipdm-pytorch_amd", "csrc", "conv_ws.hip"), "rb") as f:
+    with open(os.path.join(ROOT, "ipdm-pytorch_amd", "csrc", fname), "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
@@ -42,13 +43,18 @@ def measured_traffic():
     inside a timed run, so a committed summary under profiles/ is reported -- but ONLY one that was taken in the mode this
     process runs in and on this very kernel source (the summary records both); anything else reports null."""
     import glob
-    sha, mode = kernel_source_sha16(), conv_mode()
+    sha, mode = kernel_source_sha16(), conv_mode() + ("" if _lib_option("conv_no_wino") == 0 else "-nowino")
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
         with open(fn) as f:
             d = json.load(f)
         if d.get("kernel_source_sha16") == sha and d.get("mode") == mode:
             return int(d["traffic_bytes_per_launch"]), os.path.basename(fn)
     return None, None
+
+
+def _lib_option(name):
+    from ipdm_pytorch_amd import _lib
+    return _lib.get_option(name)
 
 
 def cpu_model():
@@ -71,6 +77,10 @@ def dominant_kernel():
         terms = 6 if split == "3" else 3
         return ("conv_sx_kernel<WM,%s> (3x3 stride-1 implicit GEMM, persistent wave-specialised, %s-piece split-bf16 = "
                 "%d bf16 MFMA terms per f32 product, f32 accumulate)" % (split, split, terms), PEAK_BF16_MFMA_TFLOPS / terms)
+    if _lib_option("conv_no_wino") == 0:
+        return ("conv_wino_kernel (wide 3x3 stride-1 convolutions in the Winograd F(2x2,3x3) domain, persistent wave-specialised, "
+                "exact-f32 MFMA; achieved counts the EXECUTED flops: 16 multiply-adds per 2x2 outputs, the 3x3 form has 36)",
+                PEAK_F32_MFMA_TFLOPS)
     return ("conv_ws_kernel<3,1,MB,NB,8> (3x3 stride-1 implicit GEMM, persistent wave-specialised, exact-f32 MFMA)",
             PEAK_F32_MFMA_TFLOPS)
 
@@ -235,22 +245,36 @@ def main():
     roofline = None
     extra = {}
     if prof:
-        fl, ms, nl = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int64 * 4)()
+        fl, ms, nl = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
         _lib.call("ipdm_profile_end", C.byref(fl), C.byref(ms), C.byref(nl))
-        if nl[0]:
-            ach = fl[0] / (ms[0] * 1e-3) / 1e12
+        # the dominant kernel: whichever form of the wide 3x3 stride-1 convolutions carries more time -- class 3 (Winograd
+        # domain, EXECUTED flops) by default, class 0 (direct form) under conv_no_wino / conv_split
+        dom = 3 if ms[3] >= ms[0] else 0
+        if nl[dom]:
+            ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
             kname, peak = dominant_kernel()
             roofline = {"kernel": kname, "bound": "mfma",
                         "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": measured_traffic()[0],
                         "traffic_source": measured_traffic()[1],
-                        "launches": int(nl[0]), "avg_launch_ms": round(ms[0] / nl[0], 4),
-                        "avg_launch_gflop": round(fl[0] / nl[0] / 1e9, 3)}
-        for c, name in ((1, "conv_other"), (2, "attention")):
+                        "launches": int(nl[dom]), "avg_launch_ms": round(ms[dom] / nl[dom], 4),
+                        "avg_launch_gflop": round(fl[dom] / nl[dom] / 1e9, 3)}
+            if dom == 3:
+                roofline["reference_form_tflops"] = round(ach * 36.0 / 16.0, 2)     # the same launches counted as 3x3 convolutions
+        other3 = 0 if dom == 3 else 3
+        for c, name in ((other3, "conv3x3_direct_form" if dom == 3 else "conv3x3_winograd"), (1, "conv_other"), (2, "attention")):
             if nl[c]:
                 extra[name] = {"tflops": round(fl[c] / (ms[c] * 1e-3) / 1e12, 2), "ms_total": round(ms[c], 2),
                                "launches": int(nl[c])}
-        extra["dominant_kernel_time_share"] = round(ms[0] * 1e-3 / elapsed, 4) if nl[0] else None
+        extra["dominant_kernel_time_share"] = round(ms[dom] * 1e-3 / elapsed, 4) if nl[dom] else None
+        if nl[4]:
+            # the bandwidth-bound kernel family: narrow direct convolutions (4/8/16 channels at 2000x912 / 1000x456)
+            gbs = fl[4] / (ms[4] * 1e-3) / 1e9
+            extra["roofline_hbm"] = {"kernel": "conv3x3_direct_kernel<CO> family (conv_direct.hip: narrow layers, packed-f32 VALU)",
+                                     "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                     "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": int(nl[4]), "ms_total": round(ms[4], 2),
+                                     "avg_launch_mb": round(fl[4] / nl[4] / 1e6, 2),
+                                     "note": "algorithmic bytes (every input, residual and output element once) / live HIP-event time"}
     if rank == 0:
         assert out.shape[0] == n_global and bool(torch.isfinite(out).all())
         value = n_global * args.steps / elapsed
@@ -269,12 +293,13 @@ def main():
                        "slices_per_gpu": B, "global_batch": n_global, "parallelism": "slice-sharded x%d" % world,
                        "rccl_ranks": idist.describe(),
                        "weights": "random-init reference architectures (29.1M img / 28.4M proj params)",
-                       "work_per_slice": "85.1 TFLOP as the reference evaluates it; 78.0 TFLOP executed here: the Upsample layers "
-                                         "(nearest 2x + 3x3 conv) run as four 2x2-tap parity convolutions over pre-added weights, "
-                                         "4 of the 9 multiply-adds per output (" + ("on" if not os.environ.get("IPDM_CONV_NO_UP2") else "OFF: IPDM_CONV_NO_UP2") +
-                                         "; DESIGN 6e); the value counts slices, roofline.achieved only 3x3 launches whose executed "
-                                         "and algorithmic FLOPs coincide"},
-            "roofline": roofline, "kernels": extra,
+                       "work_per_slice": "85.1 TFLOP as the reference evaluates it.  Executed here: the Upsample layers (nearest 2x + "
+                                         "3x3 conv) as four 2x2-tap parity convolutions over pre-added weights (4 of 9 multiply-adds per "
+                                         "output: " + ("on" if _lib_option("conv_no_up2") == 0 else "OFF") + "), the wide 3x3 stride-1 "
+                                         "convolutions in the Winograd F(2x2,3x3) domain (16 of 36: " +
+                                         ("on" if _lib_option("conv_no_wino") == 0 else "OFF") + ") -- both the same functions in exact "
+                                         "arithmetic; the value counts slices, roofline.achieved counts EXECUTED flops only"},
+            "roofline": roofline, "roofline_hbm": extra.pop("roofline_hbm", None), "kernels": extra,
         }
         line["dtype"] = {"": "f32", "3": "f32 (wide 3x3 convs: 3-piece split-bf16 operands, 6 MFMA terms, f32 accumulate)",
                          "2": "f32 (wide 3x3 convs: 2-piece split-bf16 operands, 3 MFMA terms, f32 accumulate)"}.get(

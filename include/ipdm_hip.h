@@ -258,8 +258,9 @@ int ipdm_art_project(ipdm_art_plan *plan, const float *d_volume, float *d_proj, 
 /* Per-launch HIP-event timing of the hot kernels on their launch stream (bench.py roofline leg; no
  * reference counterpart -- the reference has no profiling).  Classes: 0 = conv 3x3
  * stride-1 wide tile in its direct form, 1 = other conv variants, 2 = attention, 3 = the Winograd-domain form of
- * class 0's layers (recorded with its EXECUTED flops, 16/36 of the 3x3 count).  ipdm_profile_end needs the stream
- * synchronised; outputs are arrays of 4. */
+ * class 0's layers (recorded with its EXECUTED flops, 16/36 of the 3x3 count), 4 = the narrow direct convolutions
+ * (bandwidth-bound: `out_flops[4]` holds their algorithmic HBM BYTES).  ipdm_profile_end needs the stream
+ * synchronised; outputs are arrays of 5. */
 int ipdm_profile_begin(int32_t max_launches);
 int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches);
 

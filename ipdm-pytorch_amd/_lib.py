@@ -78,7 +78,7 @@ PROTOTYPES = {
     "ipdm_op_up_conv_chain": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp,
                                         _i32, _i32, _vp, _vp, C.POINTER(_i32), _vp]),
     "ipdm_profile_begin": (C.c_int, [_i32]),
-    "ipdm_profile_end": (C.c_int, [C.POINTER(_f64 * 4), C.POINTER(_f64 * 4), C.POINTER(_i64 * 4)]),
+    "ipdm_profile_end": (C.c_int, [C.POINTER(_f64 * 5), C.POINTER(_f64 * 5), C.POINTER(_i64 * 5)]),
     "ipdm_bench_conv2d": (C.c_int, [_i32] * 11 + [C.POINTER(_f32)]),
     "ipdm_bench_attention": (C.c_int, [_i32] * 5 + [C.POINTER(_f32)]),
     "ipdm_op_attention": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),

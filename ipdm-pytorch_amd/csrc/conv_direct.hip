@@ -29,6 +29,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// algorithmic HBM bytes of one launch (bench.py's roofline_hbm: these layers are bandwidth-bound): every input, residual and
+// output element once
+inline double direct_bytes(const ConvArgs &a)
+{
+    return 4.0 * a.B * ((double)(a.C1 + a.C2) * a.Hs * a.Ws + (double)a.Cout * a.Ho * a.Wo * (a.res ? 2 : 1));
+}
+
 constexpr int DT_W = 64, DT_H = 16;
 constexpr int DIN_P1 = 68;     // LDS row pitch at stride 1: 16-byte aligned runs of 4 (+ halo); stride 2: 132
 
@@ -336,9 +343,9 @@ int launch_direct_s2(const ConvArgs &a, hipStream_t st)
 {
     dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
     const bool prof = prof_enabled();
-    if (prof) prof_before(1, st);
+    if (prof) prof_before(4, st);
     hipLaunchKernelGGL((conv_direct_kernel<CO, 3, 2, false, 2>), grid, dim3(256), 0, st, a);
-    if (prof) prof_after(1, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * 9, st);
+    if (prof) prof_after(4, direct_bytes(a), st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }
@@ -348,10 +355,10 @@ int launch_direct(const ConvArgs &a, hipStream_t st)
 {
     dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
     const bool prof = prof_enabled();
-    if (prof) prof_before(1, st);
+    if (prof) prof_before(4, st);
     if (a.x1_planar) hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), false>), grid, dim3(256), 0, st, a);
-    if (prof) prof_after(1, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * (a.C1 + a.C2) * KS * KS, st);
+    if (prof) prof_after(4, direct_bytes(a), st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }
@@ -397,10 +404,10 @@ int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
     if (conv_direct_up2_eligible(a)) {
         dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
         const bool prof = prof_enabled();
-        if (prof) prof_before(1, st);
+        if (prof) prof_before(4, st);
         if (a.Cout <= 8) hipLaunchKernelGGL((conv_direct_up2_kernel<8, 8>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_direct_up2_kernel<16, 8>), grid, dim3(256), 0, st, a);
-        if (prof) prof_after(1, 2.0 * a.B * a.Ho * a.Wo * (double)a.Cout * a.C1 * 4, st);      // executed: 4 taps per output
+        if (prof) prof_after(4, direct_bytes(a), st);
         IPDM_LAUNCH_CHECK();
         return IPDM_OK;
     }

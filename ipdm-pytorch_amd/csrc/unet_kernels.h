@@ -65,7 +65,8 @@ int conv_ws_k_chunk(int ks, int interleave);   // K chunk of the kernel a (ks, w
 // per-launch HIP-event timing of kernel classes (bench.py roofline): 0 = conv 3x3 s1 wide tile (the
 // dominant kernel), 1 = every other conv variant, 2 = attention
 // 3 = the Winograd-domain form of class 0's layers, recorded with its EXECUTED flops (16/36 of the 3x3 count)
-constexpr int PROF_CLASSES = 4;
+// 4 = the narrow direct convolutions (conv_direct.hip), bandwidth-bound: recorded with their algorithmic HBM BYTES
+constexpr int PROF_CLASSES = 5;
 bool prof_enabled();
 void prof_before(int cls, hipStream_t st);
 void prof_after(int cls, double flops, hipStream_t st);
