@@ -55,8 +55,11 @@ constexpr int U_FLOATS = 16 * 2 * 2 * 32 * 4;
 constexpr int STAGE = V_FLOATS + U_FLOATS;             // 12288 floats = 48 KB
 constexpr int XCH_FLOATS = 4 * 8 * 64 * 4;             // per consumer wave: 8 x (64 lanes x 16 bytes)
 constexpr int STAT_FLOATS = 4 * 256;
-constexpr int XSCR_FLOATS = 4 * (16 * 36 + 64 * 4);   // the producers' activated windows: per wave 16 row segments of 36 (+ a
-                                                       // dump slot per lane for the 12 of 48 load slots that do not exist)
+constexpr int XP = 40;                                 // scratch row pitch: 34 window columns, 16-byte aligned rows, and room for the
+                                                       // stride-2 stores of a parity-planar source (columns up to 39)
+constexpr int XWAVE = 16 * XP + 64 * 4 + 8;            // per producer wave: 16 row segments + a dump slot per lane (for the load
+                                                       // slots that do not exist; + 8: the planar form stores 4 dwords at stride 2)
+constexpr int XSCR_FLOATS = 4 * XWAVE;                 // the producers' activated windows
 constexpr size_t LDS_BYTES = (size_t)(2 * STAGE + XCH_FLOATS + STAT_FLOATS + XSCR_FLOATS) * sizeof(float);
 constexpr int U_CHUNK_FLOATS = U_FLOATS;               // packed weights of one (chunk, cout tile): the U stage image
 
@@ -139,8 +142,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         const int q = lane & 3;                                          // G / W1: the lane's channel inside the group
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)a.w, 0, nchunks * a.co_tiles * U_CHUNK_FLOATS * 4, 0x00020000);
-        constexpr int XP = 36;                                           // scratch row pitch (16-byte aligned rows)
-        float *const xw = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + pw * (16 * XP + 256);
+        float *const xw = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + pw * XWAVE;
         // slot u = (lane >> 2) + 16 j  ->  (row r, 4-float part) of the lane's channel; 36 of the 48 slots exist
         int lconst[3], xoff[3];
         unsigned slot_rp[3];                                             // r | part << 4 | valid << 8 (tile-independent)
@@ -155,6 +157,25 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             xoff[j] = v ? (q * 4 + r) * XP + 4 * part : 16 * XP + lane * 4;      // (slots that do not exist: the lane's dump slot)
             slot_rp[j] = (unsigned)r | (unsigned)part << 4 | (v ? 256u : 0u);
         }
+        // A parity-planar x1 (the output of an up2 convolution: [ch][row & 1][col & 1][H/2][W/2]): a window row lies in two
+        // planes -- its even window columns (odd image columns: the window starts one pixel left of an even tile origin) and
+        // its odd ones, 17 floats each.  10 lanes per row (5 x 16 bytes per plane) instead of 9, 40 of the 48 slots; the
+        // four floats of a load are every other window column, so they go to the scratch as four dword stores.
+        int lconstp[PLANAR ? 3 : 1], xoffp[PLANAR ? 3 : 1];
+        unsigned slot_p[PLANAR ? 3 : 1];                                // r | first window column << 4 | valid << 12
+        const int h2 = a.Hs >> 1, w2 = a.Ws >> 1;
+        if (PLANAR) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int u = (lane >> 2) + 16 * j, r = u / 10, part = u - r * 10;
+                const bool v = u < 40;
+                const int px = part < 5 ? 1 : 0, py = (r + 1) & 1, yo = r == 0 ? -1 : (r == 3 ? 1 : 0);
+                const int xo = px ? 4 * part - 1 : 4 * (part - 5), c0 = px ? 8 * part : 8 * (part - 5) + 1;
+                lconstp[PLANAR ? j : 0] = v ? (((py * 2 + px) * h2 + yo) * w2 + xo) * 4 + q * plane_bytes : OOB;
+                xoffp[PLANAR ? j : 0] = v ? (q * 4 + r) * XP + c0 : 16 * XP + lane * 4;      // (dump slot; the stores reach 6 floats further)
+                slot_p[PLANAR ? j : 0] = (unsigned)r | (unsigned)c0 << 4 | (v ? 4096u : 0u);
+            }
+        }
         // per-lane LDS bases of both stages, so that every store below is base + a 16-bit immediate (no per-store VALU)
         float *const wdstP[2] = {lds + V_FLOATS + tid * 4, lds + STAGE + V_FLOATS + tid * 4};              // + e * 1024
         // tile descriptors: issue side (G) and activation side (W1, one or two chunks behind)
@@ -164,6 +185,8 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         bool g_bord = false;
         int vo[3] = {lconst[0], lconst[1], lconst[2]};                   // per-lane load offsets of the tile being loaded
         int g_so = 0;                                                    // ... and the scalar part of its window origin
+        int vop[PLANAR ? 3 : 1] = {}, g_sop = 0;                        // the same for chunks of a parity-planar x1
+        unsigned g_vmp = 0xfffu, a_vmp = 0xfffu;
         unsigned g_vm = 0xfffu, g_lsh = 0;                              // validity of the 12 loaded elements; left-edge shift
         unsigned a_vm = 0xfffu, a_lsh = 0;
         bool a_bord = false;
@@ -178,6 +201,28 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             g_so = g_bord ? 0 : g_base;
 #pragma unroll
             for (int j = 0; j < 3; ++j) vo[j] = lconst[j];
+            if (PLANAR) {
+                const int basep = (((tl.oy0 >> 1) + tyw) * w2 + (tl.ox0 >> 1)) * 4;
+                g_sop = g_bord ? 0 : basep;
+                g_vmp = 0xfffu;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) vop[PLANAR ? j : 0] = lconstp[PLANAR ? j : 0];
+                if (g_bord) {
+                    g_vmp = 0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const unsigned sp = slot_p[PLANAR ? j : 0];
+                        const int r = sp & 15, c0 = sp >> 4 & 255;
+                        const bool rowok = (sp & 4096u) && iy0 + r >= 0 && iy0 + r < a.H;
+                        vop[PLANAR ? j : 0] = rowok ? lconstp[PLANAR ? j : 0] + basep : OOB;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int c = c0 + 2 * e, ix = ix0 + c;
+                            g_vmp |= (rowok && ix >= 0 && ix < a.W && c < 34) ? 1u << (4 * j + e) : 0u;
+                        }
+                    }
+                }
+            }
             if (g_bord) {
                 g_vm = 0; g_lsh = 0;
 #pragma unroll
@@ -200,7 +245,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
                 }
             }
         };
-        struct Raw { f32x4 v[3]; float sc, sh; };
+        struct Raw { f32x4 v[3]; float sc, sh; bool planar; };
         Raw rawA, rawB;
         f32x4 wA[8], wB[8];
         // (no integer division, 64-bit address arithmetic or per-step address VALU outside the window: beside the partner's
@@ -226,10 +271,17 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(from1 ? g_src1 : g_src2), 0, (from1 ? a.C1 : a.C2) * plane_bytes, 0x00020000);
             // interior tiles: tile origin through the scalar offset (g_so), per-lane offsets fixed for the kernel; border
             // tiles: range-checked per-lane offsets; describe() put whichever applies into vo[]
-            const int so = ((from1 ? c0 : c0 - a.C1) + 4 * cg) * plane_bytes + g_so;
+            const int cb = ((from1 ? c0 : c0 - a.C1) + 4 * cg) * plane_bytes;
+            r.planar = PLANAR && from1;
+            if (PLANAR && from1) {       // (uniform) only x1 is stored parity-planar; the skip half of a concat is NCHW
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                r.v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo[j], so, 0));
+                for (int j = 0; j < 3; ++j)
+                    r.v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vop[PLANAR ? j : 0], cb + g_sop, 0));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    r.v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo[j], cb + g_so, 0));
+            }
             const int gso = (g_n * Ctot + c0 + 4 * cg) * 4;
             r.sc = bload(gsc_rsrc, q * 4, gso);
             r.sh = bload(gsh_rsrc, q * 4, gso);
@@ -241,7 +293,8 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             f32x2 d[6];
 #pragma unroll
             for (int j = 0; j < 3; ++j) { d[2 * j] = f32x2{r.v[j][0], r.v[j][1]}; d[2 * j + 1] = f32x2{r.v[j][2], r.v[j][3]}; }
-            if (a_bord) {        // (uniform) undo the left-edge shift: {x0, x1, x2, x3} loaded from one pixel further right
+            const bool pl = PLANAR && r.planar;
+            if (a_bord && !pl) {  // (uniform) undo the left-edge shift: {x0, x1, x2, x3} loaded from one pixel further right
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     if (a_lsh >> j & 1) { d[2 * j + 1] = f32x2{d[2 * j][1], d[2 * j + 1][0]}; d[2 * j] = f32x2{0.0f, d[2 * j][0]}; }
@@ -265,12 +318,21 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
                 }
             }
             if (a_bord) {
+                const unsigned vm = pl ? a_vmp : a_vm;
 #pragma unroll
-                for (int e = 0; e < 12; ++e) d[e >> 1][e & 1] = (a_vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
+                for (int e = 0; e < 12; ++e) d[e >> 1][e & 1] = (vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
             }
+            if (pl) {            // every other window column
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                *reinterpret_cast<f32x4 *>(xw + xoff[j]) = f32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
+                for (int j = 0; j < 3; ++j) {
+                    float *xd = xw + xoffp[PLANAR ? j : 0];
+                    xd[0] = d[2 * j][0]; xd[2] = d[2 * j][1]; xd[4] = d[2 * j + 1][0]; xd[6] = d[2 * j + 1][1];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    *reinterpret_cast<f32x4 *>(xw + xoff[j]) = f32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
+            }
         };
         const bool pstamp = IPDM_CONV_STAMPS && (a.dbg & 8) != 0;
         unsigned long long p_issue = 0, p_wait = 0, p_math = 0, p_hand = 0, p_t = 0;
@@ -300,7 +362,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_wait += now - p_t; p_t = now; }
             // ---- the VALU window (the consumers run W2(s) beside it)
             if (more1) {                                       // W1(s+1)
-                if (ch == nchunks - 1) { a_vm = g_vm; a_lsh = g_lsh; a_bord = g_bord; }      // chunk s+1 opens the tile described last
+                if (ch == nchunks - 1) { a_vm = g_vm; a_vmp = g_vmp; a_lsh = g_lsh; a_bord = g_bord; }      // chunk s+1 opens the tile described last
                 activate(rc);
             }
             // the next tile's descriptors, while the SIMD is still ours (its first raw loads are issued two steps from now)
@@ -318,7 +380,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         if (S > 0) {
             // prologue (nobody multiplies yet: the SIMDs are free): tile 0, G(0), G(1), W1(0), R(0)
             describe(0);
-            a_vm = g_vm; a_lsh = g_lsh; a_bord = g_bord;
+            a_vm = g_vm; a_vmp = g_vmp; a_lsh = g_lsh; a_bord = g_bord;
             issue_w(0, wA);
             issue_raw(0, rawB);
             issue_raw(1, rawA);                                // (nchunks >= 4: chunk 1 belongs to tile 0)
@@ -359,13 +421,13 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
     // scratch -- lane map 16 tiles x 2 k-steps x 2 channel parities, so that the 32 lanes of an LDS store group write a
     // 64-float span of the [tile][k-step] image at most 2-way conflicted (free)
     const int w_t16 = lane & 15, w_kpl = (lane >> 4) & 1;
-    const float *const xr = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + swave * (16 * 36 + 256) + ((2 * w_kpl + lk) * 4) * 36 + 2 * w_t16;
+    const float *const xr = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + swave * XWAVE + ((2 * w_kpl + lk) * 4) * XP + 2 * w_t16;
     const int v_lane = (lk * 32 + 16 * (swave & 1) + w_t16) * 4 + 2 * (swave >> 1) + w_kpl;      // + xi * 256 (+ stage)
     float patch[16];
     auto read_patch = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f32x2 lo = *reinterpret_cast<const f32x2 *>(xr + r * 36), hi = *reinterpret_cast<const f32x2 *>(xr + r * 36 + 2);
+            const f32x2 lo = *reinterpret_cast<const f32x2 *>(xr + r * XP), hi = *reinterpret_cast<const f32x2 *>(xr + r * XP + 2);
             patch[4 * r] = lo[0]; patch[4 * r + 1] = lo[1]; patch[4 * r + 2] = hi[0]; patch[4 * r + 3] = hi[1];
         }
     };
@@ -578,7 +640,7 @@ bool conv_wino_eligible(const ConvArgs &a)
     if (a.w_interleave != 2 && a.w_interleave != 4) return false;
     const int Ctot = a.C1 + a.C2;
     if (a.Cout % BN || Ctot % KC || Ctot < 32 || (a.C2 && a.C1 % KC)) return false;
-    if (a.x1_planar || conv_up2_eligible(a)) return false;      // (parity-planar inputs stay on the direct kernel)
+    if ((a.x1_planar && ((a.Hs | a.Ws) & 1)) || conv_up2_eligible(a)) return false;
     return conv_ws_split(a) == 1;
 }
 

@@ -603,6 +603,9 @@ def test_fused_groupnorm_statistics_with_a_large_channel_offset(offset):
     (1, 4, 9, 11, 4, 0, 4, 3, 0),                 # 4 channels: not eligible, 3x3 form with nearest addressing
     (1, 256, 4, 4, 256, 0, 256, 3, 1),            # 256 channels at 8x8: reader with a K split
     (1, 128, 228, 500, 128, 16, 16, 3, 2),        # production size (transposed sinogram level 500x228 -> 1000x456) and its 144 -> 16 reader
+    (1, 128, 40, 72, 128, 64, 128, 3, 2),         # Winograd-domain reader of a parity-planar source, concatenated skip (80x144)
+    (2, 64, 33, 47, 64, 0, 64, 3, 2),             # ... ragged tiles on both axes (66x94), border tiles on all sides
+    (1, 64, 34, 50, 64, 64, 64, 3, 1),            # ... GroupNorm without SiLU, 68x100
 ])
 def test_upsample_conv_parity_form(case):
     """Upsample (nearest 2x + 3x3 conv) evaluated as four 2x2-tap convolutions over the source grid (the taps that fall on
