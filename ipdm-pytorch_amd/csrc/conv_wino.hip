@@ -159,8 +159,10 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         }
         // A parity-planar x1 (the output of an up2 convolution: [ch][row & 1][col & 1][H/2][W/2]): a window row lies in two
         // planes -- its even window columns (odd image columns: the window starts one pixel left of an even tile origin) and
-        // its odd ones, 17 floats each.  10 lanes per row (5 x 16 bytes per plane) instead of 9, 40 of the 48 slots; the
-        // four floats of a load are every other window column, so they go to the scratch as four dword stores.
+        // its odd ones, 17 floats each.  10 lanes per row (5 x 16 bytes per plane) instead of 9, 40 of the 48 slots.  The
+        // four floats of a load are every other window column; the scratch row keeps them de-interleaved -- [even columns:
+        // 20][odd columns: 20] -- so that the store stays one ds_write_b128 (as four stride-2 dword stores they were 8-way
+        // bank conflicts, the window LDS-bound), and the consumers gather their patches with ds_read2_b32.
         int lconstp[PLANAR ? 3 : 1], xoffp[PLANAR ? 3 : 1];
         unsigned slot_p[PLANAR ? 3 : 1];                                // r | first window column << 4 | valid << 12
         const int h2 = a.Hs >> 1, w2 = a.Ws >> 1;
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
                 const int px = part < 5 ? 1 : 0, py = (r + 1) & 1, yo = r == 0 ? -1 : (r == 3 ? 1 : 0);
                 const int xo = px ? 4 * part - 1 : 4 * (part - 5), c0 = px ? 8 * part : 8 * (part - 5) + 1;
                 lconstp[PLANAR ? j : 0] = v ? (((py * 2 + px) * h2 + yo) * w2 + xo) * 4 + q * plane_bytes : OOB;
-                xoffp[PLANAR ? j : 0] = v ? (q * 4 + r) * XP + c0 : 16 * XP + lane * 4;      // (dump slot; the stores reach 6 floats further)
+                xoffp[PLANAR ? j : 0] = v ? (q * 4 + r) * XP + (px ? 4 * part : 20 + 4 * (part - 5)) : 16 * XP + lane * 4;      // (else: dump slot)
                 slot_p[PLANAR ? j : 0] = (unsigned)r | (unsigned)c0 << 4 | (v ? 4096u : 0u);
             }
         }
@@ -322,12 +324,10 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
 #pragma unroll
                 for (int e = 0; e < 12; ++e) d[e >> 1][e & 1] = (vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
             }
-            if (pl) {            // every other window column
+            if (pl) {            // every other window column: the de-interleaved half of the scratch row
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    float *xd = xw + xoffp[PLANAR ? j : 0];
-                    xd[0] = d[2 * j][0]; xd[2] = d[2 * j][1]; xd[4] = d[2 * j + 1][0]; xd[6] = d[2 * j + 1][1];
-                }
+                for (int j = 0; j < 3; ++j)
+                    *reinterpret_cast<f32x4 *>(xw + xoffp[PLANAR ? j : 0]) = f32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
             } else {
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
@@ -424,11 +424,20 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
     const float *const xr = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + swave * XWAVE + ((2 * w_kpl + lk) * 4) * XP + 2 * w_t16;
     const int v_lane = (lk * 32 + 16 * (swave & 1) + w_t16) * 4 + 2 * (swave >> 1) + w_kpl;      // + xi * 256 (+ stage)
     float patch[16];
-    auto read_patch = [&]() __attribute__((always_inline)) {
+    const float *const xrp = xr - w_t16;                    // planar chunks: [even window columns: 20][odd: 20], column pair t16, t16 + 1
+    auto read_patch = [&](bool planar) __attribute__((always_inline)) {
+        if (PLANAR && planar) {      // (uniform)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const f32x2 lo = *reinterpret_cast<const f32x2 *>(xr + r * XP), hi = *reinterpret_cast<const f32x2 *>(xr + r * XP + 2);
-            patch[4 * r] = lo[0]; patch[4 * r + 1] = lo[1]; patch[4 * r + 2] = hi[0]; patch[4 * r + 3] = hi[1];
+            for (int r = 0; r < 4; ++r) {
+                patch[4 * r] = xrp[r * XP]; patch[4 * r + 2] = xrp[r * XP + 1];
+                patch[4 * r + 1] = xrp[r * XP + 20]; patch[4 * r + 3] = xrp[r * XP + 21];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x2 lo = *reinterpret_cast<const f32x2 *>(xr + r * XP), hi = *reinterpret_cast<const f32x2 *>(xr + r * XP + 2);
+                patch[4 * r] = lo[0]; patch[4 * r + 1] = lo[1]; patch[4 * r + 2] = hi[0]; patch[4 * r + 3] = hi[1];
+            }
         }
     };
     const int a_off = V_FLOATS + ((((8 * ih) * 2 + h) * 2 + lk) * 32 + l31) * 4;      // + e * 512 floats
@@ -442,7 +451,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
     int k = 0, ch = -1;                                    // running (tile, chunk in tile): no division in the MFMA wave
     if (S > 0) {
         __syncthreads();                                   // P: the producers' prologue has put X(0) into the scratch
-        read_patch();                                      // (window 0 overwrites it with X(1): read before barrier A_0)
+        read_patch(PLANAR);                                // (window 0 overwrites it with X(1): read before barrier A_0; chunk 0 is x1's)
     }
     for (int s = 0; s < S; ++s) {
         if (++ch == nchunks) { ch = 0; ++k; }
@@ -471,7 +480,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                   // hand-over: stage (s&1) is complete
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < S) read_patch();                       // R(s+1): written in this window, used in the next one
+        if (s + 1 < S) read_patch(PLANAR && (ch + 1 == nchunks ? 0 : ch + 1) * KC < a.C1);      // R(s+1): written in this window, used in the next one
         if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_bar += now - t_last; t_last = now; }
         if (ch == 0) {
 #pragma unroll

@@ -1273,6 +1273,8 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
                                  int32_t stride, int32_t act, int32_t with_res, int32_t iters, float *avg_ms)
 {
     IPDM_REQUIRE(avg_ms && iters > 0, "bench_conv2d: bad argument");
+    const bool x1_planar = (act & 256) != 0;          // tuning aid: time the kernel's parity-planar reader path (x1 as an up2 output)
+    act &= 255;
     const int Cin = C1 + C2, pad = ksize / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     std::vector<float> w((size_t)Cout * Cin * ksize * ksize), packed;
@@ -1302,6 +1304,7 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     a.scale_y = a.scale_x = 1.f; a.w = d_w; a.w_wino = d_wino; a.cout_pad = cout_pad; a.w_interleave = interleave; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
     a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
     a.tiles_x = a.tiles_y = a.co_tiles = 0;
+    if (x1_planar) { IPDM_REQUIRE(conv_planar_ok(a), "bench_conv2d: this shape has no parity-planar reader"); a.x1_planar = 1; }
     float *d_split = nullptr;
     if (conv_split_ws_bytes(a)) IPDM_HIP_CHECK(hipMalloc((void **)&d_split, conv_split_ws_bytes(a)));
     a.split_ws = d_split;

@@ -61,7 +61,8 @@ def run(B, C1, C2, H, W, Cout, act, res, seed=1):
     return wm / sc
 
 
-def bench(B, C1, C2, H, W, Cout, act, res, iters=20):
+def bench(B, C1, C2, H, W, Cout, act, res, iters=20, planar=False):
+    act = act | (256 if planar else 0)
     ms = {}
     for rep in range(2):
         for mode in (0, 1):
@@ -71,7 +72,8 @@ def bench(B, C1, C2, H, W, Cout, act, res, iters=20):
             ms.setdefault(mode, []).append(t.value)
     fl = 2.0 * B * H * W * Cout * (C1 + C2) * 9
     a, b = min(ms[0]), min(ms[1])
-    print("bench B%d %d+%d->%d @%dx%d act%d res%d: wino %.3f ms (%.1f TF/s-equivalent) direct %.3f ms (%.1f TF/s)  speedup %.2fx" % (
+    act &= 255
+    print(("planar " if planar else "") + "bench B%d %d+%d->%d @%dx%d act%d res%d: wino %.3f ms (%.1f TF/s-equivalent) direct %.3f ms (%.1f TF/s)  speedup %.2fx" % (
         B, C1, C2, Cout, H, W, act, int(res), a, fl / a / 1e9, b, fl / b / 1e9, b / a), flush=True)
 
 
@@ -101,6 +103,13 @@ def main():
         return
     bench(8, 128, 0, 512, 512, 128, 2, True)
     if quick:
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "planar":
+        for pl in (False, True):
+            bench(8, 64, 64, 512, 512, 64, 2, False, planar=pl)
+            bench(8, 128, 64, 256, 256, 64, 2, False, planar=pl)
+            bench(8, 128, 128, 128, 128, 128, 2, False, planar=pl)
+            bench(8, 128, 128, 228, 500, 128, 2, False, planar=pl)
         return
     bench(8, 64, 0, 512, 512, 64, 2, True)
     bench(8, 128, 0, 512, 512, 128, 0, False)
