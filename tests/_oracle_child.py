@@ -2,7 +2,7 @@
 (oracle.pipeline.progressive_slice) with the draws the device recorded, and saves the result.  Several of these run side
 by side (one per slice / seed) so that a 75-forward oracle run fits the GPU test budget.  Never touches the GPU.
 
-  python tests/_oracle_child.py job.npz out.npy n_threads
+  python tests/_oracle_child.py job.npz out.npy n_threads [cpu,cpu,...]
 """
 import json
 import os
@@ -30,13 +30,25 @@ def write_job(path, opt_dict, sino, draws, weight_seed, sharpen_num):
              opt=json.dumps({k: opt_dict[k] for k in OPT_KEYS}), weight_seed=weight_seed, sharpen_num=sharpen_num)
 
 
+def cpu_blocks(njobs, threads):
+    """Disjoint blocks of `threads` logical CPUs for njobs side-by-side children, spread over the first half of the CPU
+    list (on the GPU boxes -- 2 x 64 cores x 2 SMT -- the physical cores of both sockets; SMT siblings are the second half):
+    unpinned, five 32-thread torch processes ran 7x slower than one alone (memory-bandwidth and thread migration)."""
+    ncpu = os.cpu_count() or 8
+    phys = ncpu // 2 if ncpu >= 16 else ncpu
+    threads = max(1, min(threads, phys // max(1, njobs)))
+    stride = phys // njobs
+    return threads, [list(range(i * stride, i * stride + threads)) for i in range(njobs)]
+
+
 def run_jobs(jobs, threads):
-    """jobs: [(job.npz, out.npy)]; runs them as parallel child processes, returns the outputs."""
+    """jobs: [(job.npz, out.npy)]; runs them as parallel, CPU-pinned child processes, returns the outputs."""
     import subprocess
     import numpy as np
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), j, o, str(threads)], env=env, cwd=ROOT,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for j, o in jobs]
+    threads, blocks = cpu_blocks(len(jobs), threads)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), j, o, str(threads), ",".join(map(str, blk))], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for (j, o), blk in zip(jobs, blocks)]
     outs = []
     for p, (j, o) in zip(procs, jobs):
         log, _ = p.communicate(timeout=1500)
@@ -47,6 +59,11 @@ def run_jobs(jobs, threads):
 
 def main():
     job, out, threads = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    if len(sys.argv) > 4 and sys.argv[4]:
+        try:
+            os.sched_setaffinity(0, {int(c) for c in sys.argv[4].split(",")})
+        except (OSError, ValueError):
+            pass
     import numpy as np
     import torch
     torch.set_num_threads(threads)

@@ -17,11 +17,16 @@ from tests.golden.cases import SMALL_CFGS, SMALL_SHAPES, LOOP_CFG, LOOP_CASES, n
 
 DEV = "cuda:0"
 
-# End-to-end max-abs budget of two float32 evaluations of the same sample ("the arbiter"): each of them
-# -- the CPU oracle as much as this library -- sits 2-3e-4 (relative to the output scale, max over 262k pixels; rms 4e-6)
-# from the float64 value of the same function on the reduced pipeline (test_smoke_pipeline_fp64_arbiter measures both
-# distances live), so two of them may differ by the sum.  PSNR, north_star's criterion, is asserted at 1e-4 relative.
+# End-to-end max-abs budget of two float32 evaluations of the REDUCED (smoke) pipeline, whose random-weight networks amplify
+# float32 rounding ~100x in one of the image-domain passes ("the arbiter"): the CPU oracle itself sits
+# 2.8e-4 / 0.83 = 3.4e-4 (relative to the output scale; max over 262k pixels, rms 8e-6) from the float64 value of the same
+# function, this library 3.8e-4 / 0.83 (test_smoke_pipeline_fp64_arbiter measures both live and bounds the library's by 1.5x
+# the oracle's).  Two such evaluations may differ by up to the sum; a bound below the oracle's own distance to the truth
+# (the 2e-4 of round 1) tests luck, not the library.  Measured |hip - oracle|: 1.4e-4 .. 2.8e-4 across builds.
 E2E_MAX_REL = 6e-4
+# The production networks at full size do not amplify like that: 1.3e-6 .. 1.9e-5 measured (5 seeds x few steps; the
+# headline length).  PSNR, north_star's criterion, is asserted at 1e-4 relative everywhere.
+FULL_SIZE_MAX_REL = 1e-4
 
 
 def _dev(a):
@@ -919,7 +924,7 @@ def test_smoke_pipeline_matches_oracle_psnr():
     # the sum, E2E_MAX_REL; the rms sits two orders of magnitude below; north_star's acceptance metric is the PSNR below.
     err = np.abs(got - want)
     assert err.max() <= E2E_MAX_REL * max(1.0, np.abs(want).max()), float(err.max())
-    assert np.sqrt((err.astype(np.float64) ** 2).mean()) <= 5e-5, float(np.sqrt((err.astype(np.float64) ** 2).mean()))
+    assert np.sqrt((err.astype(np.float64) ** 2).mean()) <= 2e-5, float(np.sqrt((err.astype(np.float64) ** 2).mean()))
     truth = od.miu2pixel(torch.from_numpy(synth.rasterize(synth.ellipse_phantom(1)))).numpy()
     p_hip = od.psnr(truth, od.miu2pixel(torch.from_numpy(got[0, 0])).numpy())
     p_cpu = od.psnr(truth, od.miu2pixel(torch.from_numpy(want[0, 0])).numpy())
@@ -935,6 +940,7 @@ def test_smoke_pipeline_fp64_arbiter():
     from ipdm_pytorch_amd.denoiser import smoke_pipeline
     from oracle import pipeline as op
     got, inputs = smoke_pipeline(DEV)
+    torch.set_num_threads(min(64, max(8, (os.cpu_count() or 8) // 2)))
     w32 = op.smoke_pipeline_oracle(inputs)
     w64 = op.smoke_pipeline_oracle(inputs, dtype=torch.float64)
     assert w64.dtype == np.float64
@@ -1199,8 +1205,8 @@ def test_full_size_pipeline_psnr(tmp_path):
         got, jobs = _full_size_run(dict(t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=False), seed, [4 + k], tmp_path,
                                    "s%d" % seed)
         runs.append((got, jobs[0], 4 + k))
-    wants = oc.run_jobs([j for _, j, _ in runs], threads=max(4, min(32, (os.cpu_count() or 8) // 5)))
-    report = [_check_full_size(got, want, ph, E2E_MAX_REL) for (got, _, ph), want in zip(runs, wants)]
+    wants = oc.run_jobs([j for _, j, _ in runs], threads=16)
+    report = [_check_full_size(got, want, ph, FULL_SIZE_MAX_REL) for (got, _, ph), want in zip(runs, wants)]
     print("full-size 5 seeds: max-abs %s rms %s" % (["%.2e" % r[0] for r in report], ["%.2e" % r[1] for r in report]))
 
 
@@ -1212,8 +1218,8 @@ def test_headline_configuration_full_length(tmp_path):
     from tests import _oracle_child as oc
     got, jobs = _full_size_run(dict(t_start_proj=[15, 15, 15], t_start_img=[15], ultra_img_denoise=True), 1234, [0, 1], tmp_path,
                                "headline")
-    wants = oc.run_jobs(jobs, threads=max(4, min(64, (os.cpu_count() or 8) // 2)))
-    report = [_check_full_size(got[b:b + 1], wants[b], b, E2E_MAX_REL) for b in range(2)]
+    wants = oc.run_jobs(jobs, threads=32)
+    report = [_check_full_size(got[b:b + 1], wants[b], b, FULL_SIZE_MAX_REL) for b in range(2)]
     msg = "headline full length B=2: " + "; ".join(
         "slice %d max-abs %.3e rms %.3e PSNR hip %.4f / cpu %.4f dB" % ((b,) + report[b]) for b in range(2))
     print(msg)
