@@ -54,13 +54,14 @@ constexpr int V_FLOATS = 16 * 2 * 32 * 4;
 constexpr int U_FLOATS = 16 * 2 * 2 * 32 * 4;
 constexpr int STAGE = V_FLOATS + U_FLOATS;             // 12288 floats = 48 KB
 constexpr int XCH_FLOATS = 4 * 8 * 64 * 4;             // per consumer wave: 8 x (64 lanes x 16 bytes)
-constexpr int STAT_FLOATS = 4 * 256;
+constexpr int STAT_FLOATS = 4 * 128;                   // per consumer wave: 2 pixel rows x 32 couts x {sum, sum of squares}
 constexpr int XP = 40;                                 // scratch row pitch: 34 window columns, 16-byte aligned rows, and room for the
                                                        // stride-2 stores of a parity-planar source (columns up to 39)
 constexpr int XWAVE = 16 * XP + 64 * 4 + 8;            // per producer wave: 16 row segments + a dump slot per lane (for the load
                                                        // slots that do not exist; + 8: the planar form stores 4 dwords at stride 2)
-constexpr int XSCR_FLOATS = 4 * XWAVE;                 // the producers' activated windows
+constexpr int XSCR_FLOATS = 2 * 4 * XWAVE;             // the producers' activated windows, double-buffered by chunk parity
 constexpr size_t LDS_BYTES = (size_t)(2 * STAGE + XCH_FLOATS + STAT_FLOATS + XSCR_FLOATS) * sizeof(float);
+static_assert(LDS_BYTES <= 160 * 1024, "conv_wino: LDS budget exceeded");
 constexpr int U_CHUNK_FLOATS = U_FLOATS;               // packed weights of one (chunk, cout tile): the U stage image
 
 struct TileId { int n, oy0, ox0, co0; };
@@ -142,7 +143,8 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         const int q = lane & 3;                                          // G / W1: the lane's channel inside the group
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)a.w, 0, nchunks * a.co_tiles * U_CHUNK_FLOATS * 4, 0x00020000);
-        float *const xw = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + pw * XWAVE;
+        float *const xwP[2] = {lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + pw * XWAVE,
+                               lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + (4 + pw) * XWAVE};      // scratch of even / odd chunks
         // slot u = (lane >> 2) + 16 j  ->  (row r, 4-float part) of the lane's channel; 36 of the 48 slots exist
         int lconst[3], xoff[3];
         unsigned slot_rp[3];                                             // r | part << 4 | valid << 8 (tile-independent)
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             r.sh = bload(gsh_rsrc, q * 4, gso);
         };
         // W1: activate the 12 landed values, zero what lies outside the image, park them in the wave's scratch
-        auto activate = [&](Raw &r) __attribute__((always_inline)) {
+        auto activate = [&](Raw &r, float *xw) __attribute__((always_inline)) {
             // pairs: the four non-transcendental operations of an element are packed-f32 instructions (the window's cost
             // is its instruction count: ~10 cycles per instruction of a lone wave, stamps)
             f32x2 d[6];
@@ -352,27 +354,23 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
 #pragma unroll
             for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x4 *>(wdstP[PAR] + e * 1024) = wc[e];
             if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_issue += now - p_t; p_t = now; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // E (the consumers' exchange barrier of the tile that just ended) already says "the matrix pipe is idle": the
-            // window of a tile's first chunk then overlaps the consumers' store epilogue instead of following it
+            // W1(s+1) beside the consumers' MFMAs of chunk s-1: no barrier in front of it.  The scratch is double-buffered by
+            // chunk parity (the consumers fetched X(s) from the other half right after the previous hand-over), the stage
+            // half written above was last read two chunks ago.  A producer's VALU only gets the stall gaps of the MFMA wave it
+            // shares a SIMD with -- the Winograd stream has one every four MFMAs -- and costs that stream nothing; the window in
+            // which the consumers used to wait for this burst (barrier A) is gone.
             const bool after_tile = ch == 0 && s > 0;
-            __builtin_amdgcn_sched_barrier(0);             // (the scheduler may not lift the window's register-only VALU above
-            __syncthreads();                               //  the barrier) E (after a tile) or A: consumers have finished chunk s-1
-            __builtin_amdgcn_sched_barrier(0);
-            if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_wait += now - p_t; p_t = now; }
-            // ---- the VALU window (the consumers run W2(s) beside it)
-            if (more1) {                                       // W1(s+1)
+            if (more1) {
                 if (ch == nchunks - 1) { a_vm = g_vm; a_vmp = g_vmp; a_lsh = g_lsh; a_bord = g_bord; }      // chunk s+1 opens the tile described last
-                activate(rc);
+                activate(rc, xwP[PAR ^ 1]);
             }
-            // the next tile's descriptors, while the SIMD is still ours (its first raw loads are issued two steps from now)
+            // the next tile's descriptors (its first raw loads are issued two steps from now)
             if (ch == nchunks - 3 && k + 1 < n_my) describe(k + 1);
             if (pstamp) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                           const unsigned long long now = __builtin_amdgcn_s_memtime(); p_math += now - p_t; p_t = now; }
-            __builtin_amdgcn_sched_barrier(0);
-            if (after_tile) __syncthreads();               // A (the consumers arrive after their stores)
-            __syncthreads();                               // hand-over: stage (s&1) is complete
-            __builtin_amdgcn_sched_barrier(0);
+            if (after_tile) __syncthreads();               // E: the consumers' exchange barrier of the tile that just ended
+            __syncthreads();                               // hand-over: stage (s&1) and X(s+1) are complete
+            if (pstamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); p_wait += now - p_t; p_t = now; }
             ch = ch1;
             k += ch1 == 0 ? 1 : 0;
             if (pstamp) p_hand += __builtin_amdgcn_s_memtime() - p_t;
@@ -385,7 +383,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             issue_raw(0, rawB);
             issue_raw(1, rawA);                                // (nchunks >= 4: chunk 1 belongs to tile 0)
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            activate(rawB);
+            activate(rawB, xwP[0]);
             __syncthreads();                                   // P: X(0) is in the scratch; the consumers fetch their patches
             for (int s = 0; s < S; s += 2) {
                 step(s, std::integral_constant<int, 0>{}, wA, wB, rawA, rawB);
@@ -421,11 +419,12 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
     // scratch -- lane map 16 tiles x 2 k-steps x 2 channel parities, so that the 32 lanes of an LDS store group write a
     // 64-float span of the [tile][k-step] image at most 2-way conflicted (free)
     const int w_t16 = lane & 15, w_kpl = (lane >> 4) & 1;
-    const float *const xr = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + swave * XWAVE + ((2 * w_kpl + lk) * 4) * XP + 2 * w_t16;
+    const float *const xr0 = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + swave * XWAVE + ((2 * w_kpl + lk) * 4) * XP + 2 * w_t16;
     const int v_lane = (lk * 32 + 16 * (swave & 1) + w_t16) * 4 + 2 * (swave >> 1) + w_kpl;      // + xi * 256 (+ stage)
     float patch[16];
-    const float *const xrp = xr - w_t16;                    // planar chunks: [even window columns: 20][odd: 20], column pair t16, t16 + 1
-    auto read_patch = [&](bool planar) __attribute__((always_inline)) {
+    auto read_patch = [&](bool planar, int par) __attribute__((always_inline)) {
+        const float *const xr = xr0 + par * (4 * XWAVE);                            // the scratch half of the chunk's parity
+        const float *const xrp = xr - w_t16;                // planar chunks: [even window columns: 20][odd: 20], column pair t16, t16 + 1
         if (PLANAR && planar) {      // (uniform)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -451,13 +450,10 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
     int k = 0, ch = -1;                                    // running (tile, chunk in tile): no division in the MFMA wave
     if (S > 0) {
         __syncthreads();                                   // P: the producers' prologue has put X(0) into the scratch
-        read_patch(PLANAR);                                // (window 0 overwrites it with X(1): read before barrier A_0; chunk 0 is x1's)
+        read_patch(PLANAR, 0);                             // (chunk 0 is x1's)
     }
     for (int s = 0; s < S; ++s) {
         if (++ch == nchunks) { ch = 0; ++k; }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                   // A: chunk s-1 done -> the SIMD is free for the window
-        __builtin_amdgcn_sched_barrier(0);
         {
             // W2(s): B^T d B of the lane's 4x4 patch (read from the producers' scratch one chunk ago, beside the MFMAs)
             float tt[16];
@@ -480,7 +476,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                   // hand-over: stage (s&1) is complete
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < S) read_patch(PLANAR && (ch + 1 == nchunks ? 0 : ch + 1) * KC < a.C1);      // R(s+1): written in this window, used in the next one
+        if (s + 1 < S) read_patch(PLANAR && (ch + 1 == nchunks ? 0 : ch + 1) * KC < a.C1, (s + 1) & 1);      // R(s+1): used after the MFMAs
         if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_bar += now - t_last; t_last = now; }
         if (ch == 0) {
 #pragma unroll
@@ -559,7 +555,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         const bool part = ragged && rok && nval > 0 && nval < 4;
         const int so0 = ((t.co0 + h * 32) * out_plane + min(t.oy0, a.Ho - 1) * a.Wo + t.ox0) * 4;
         const float *xr2 = xch + ((swave ^ 1) * 8) * 256 + lane * 4;
-        float *sb = stat_lds + swave * 256;
+        float *sb = stat_lds + swave * 128;
 #define IPDM_SWAP1(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0xB1, 0xf, 0xf, false))
 #define IPDM_ROR(v, c) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (c), 0xf, 0xf, false))
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
