@@ -825,11 +825,28 @@ static int conv2d_ws_dispatch(const ConvArgs &a, hipStream_t st)
     }
     if (a.ksize == 3 && a.stride == 1 && a.w_interleave == 2) return launch_ws<3, 1, 2, 4, 8>(a, st, 0);
     // Downsample (3x3 stride 2): same kernel, input tile (2*TH+1) x 65 per channel
-    if (a.ksize == 3 && a.stride == 2 && a.w_interleave == 4) return launch_ws<3, 2, 4, 2, 8>(a, st, 1);
+    if (a.ksize == 3 && a.stride == 2 && a.w_interleave == 4) {
+        // (under-filled launches on quarter tiles, as for the 1x1 and stride-1 kernels: one slice alone at 250x114 -> 125x57)
+        const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 8) * cdiv(a.Cout, 128) * a.B;
+        if (tiles < 128 && !opt(OPT_CONV1X1_NO_QUARTER)) return launch_ws<3, 2, 2, 1, 8, 4>(a, st, 1);
+        return launch_ws<3, 2, 4, 2, 8>(a, st, 1);
+    }
     if (a.ksize == 3 && a.stride == 2 && a.w_interleave == 2) return launch_ws<3, 2, 2, 2, 8>(a, st, 1);
     // 1x1: a plain GEMM over channels; 32-channel chunks give the producers 8k cycles of MFMA per hand-over
-    if (a.ksize == 1 && a.stride == 1 && a.w_interleave == 4) return launch_ws<1, 1, 4, 2, 32>(a, st, 1);
-    if (a.ksize == 1 && a.stride == 1 && a.w_interleave == 2) return launch_ws<1, 1, 2, 4, 32>(a, st, 1);
+    if (a.ksize == 1 && a.stride == 1) {
+        // launches that leave most of the chip idle (one slice alone on the low-resolution levels: 64 tiles of 8x32x128 for
+        // 256 channels at 125x57) run on quarter tiles (4x32 pixels x 64 couts) over the same packed weights: 4x the
+        // workgroups, the same K order per output -- the choice looks at the batch and does not change a bit, like the 3x3
+        // variant above.  B = 1: 256->256 @125x57 0.059 -> see DESIGN section 6
+        const int rows = a.w_interleave == 4 ? 8 : 16;
+        const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, rows) * cdiv(a.Cout, 32 * a.w_interleave) * a.B * (a.ksplit > 1 ? a.ksplit : 1);
+        if (tiles < 128 && !opt(OPT_CONV1X1_NO_QUARTER)) {
+            if (a.w_interleave == 4) return launch_ws<1, 1, 2, 1, 32, 4>(a, st, 1);
+            return launch_ws<1, 1, 2, 1, 32, 2>(a, st, 1);
+        }
+        if (a.w_interleave == 4) return launch_ws<1, 1, 4, 2, 32>(a, st, 1);
+        return launch_ws<1, 1, 2, 4, 32>(a, st, 1);
+    }
     set_error("conv2d_ws: unsupported ksize=%d stride=%d interleave=%d", a.ksize, a.stride, a.w_interleave);
     return IPDM_ERR_UNSUPPORTED;
 }
