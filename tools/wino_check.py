@@ -100,6 +100,8 @@ def main():
             bench(8, 128, 0, 512, 512, 128, 2, True, iters=3)
             bench(8, 128, 0, 512, 512, 128, 0, False, iters=3)
             bench(8, 64, 0, 512, 512, 64, 2, True, iters=3)
+            for pl in (False, True):             # the same concat layer from an NCHW / a parity-planar x1
+                bench(8, 64, 64, 512, 512, 64, 2, False, iters=3, planar=pl)
         return
     bench(8, 128, 0, 512, 512, 128, 2, True)
     if quick:
