@@ -41,6 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef IPDM_CONV_STAMPS
 #define IPDM_CONV_STAMPS 0          // `make stamps`: in-kernel s_memtime stamps of the phases (a stamped build changes what it measures)
@@ -60,11 +61,17 @@ constexpr int XP = 40;                                 // scratch row pitch: 34 
 constexpr int XWAVE = 16 * XP + 64 * 4 + 8;            // per producer wave: 16 row segments + a dump slot per lane (for the load
                                                        // slots that do not exist; + 8: the planar form stores 4 dwords at stride 2)
 constexpr int XSCR_FLOATS = 2 * 4 * XWAVE;             // the producers' activated windows, double-buffered by chunk parity
-constexpr size_t LDS_BYTES = (size_t)(2 * STAGE + XCH_FLOATS + STAT_FLOATS + XSCR_FLOATS) * sizeof(float);
+constexpr int TDESC_FLOATS = 8;                        // {sample, cout origin, row origin, column origin} of the tiles k, k + 1 (by parity)
+constexpr size_t LDS_BYTES = (size_t)(2 * STAGE + XCH_FLOATS + STAT_FLOATS + XSCR_FLOATS + TDESC_FLOATS) * sizeof(float);
 static_assert(LDS_BYTES <= 160 * 1024, "conv_wino: LDS budget exceeded");
 constexpr int U_CHUNK_FLOATS = U_FLOATS;               // packed weights of one (chunk, cout tile): the U stage image
 
 struct TileId { int n, oy0, ox0, co0; };
+
+// The stage images keep the rows i of the 4x4 transform domain in the order 0, 1, 3, 2: consumer wave ih then holds rows
+// (0, 1) or (3, 2) in its accumulators 0-3 / 4-7, and in the output transform BOTH waves keep first + second and send the
+// second (T1 resp. T2) -- no wave-dependent selects.
+__host__ __device__ constexpr int row_slot(int i) { return i ^ (i >> 1); }
 
 __device__ inline TileId decode_tile(const ConvArgs &a, int tile)
 {
@@ -106,6 +113,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *const xch = lds + 2 * STAGE;
     float *const stat_lds = xch + XCH_FLOATS;
+    int *const tdesc = reinterpret_cast<int *>(lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + XSCR_FLOATS);
 
     // static tile schedule of conv_ws.hip: the workgroups of one XCD take a contiguous run of tiles, slot rotated per round
     const int G = gridDim.x, per = G >> 3;
@@ -156,7 +164,10 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             //  next row, or -- at the very end of the tensor -- dwords past num_records, which a raw buffer load range-checks
             //  one by one and returns as 0 (tools/ubench/oob_probe.hip); they land in the scratch rows' padding)
             lconst[j] = v ? (r * a.Ws + 4 * part) * 4 + q * plane_bytes : OOB;
-            xoff[j] = v ? (q * 4 + r) * XP + 4 * part : 16 * XP + lane * 4;      // (slots that do not exist: the lane's dump slot)
+            // (slots that do not exist: the lane's dump slot; in the PLANAR instantiation every scratch row is de-interleaved,
+            //  [even window columns: 20][odd: 20], also for the NCHW half of a concat: see below)
+            //  (its dump stores go to +0, +1, +20, +21: two floats per lane keep them inside the dump area)
+            xoff[j] = v ? (q * 4 + r) * XP + (PLANAR ? 2 : 4) * part : 16 * XP + lane * (PLANAR ? 2 : 4);
             slot_rp[j] = (unsigned)r | (unsigned)part << 4 | (v ? 256u : 0u);
         }
         // A parity-planar x1 (the output of an up2 convolution: [ch][row & 1][col & 1][H/2][W/2]): a window row lies in two
@@ -198,6 +209,9 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             const TileId tl = decode_tile(a, tile_of(k));
             const int iy0 = tl.oy0 - 1 + 2 * tyw, ix0 = tl.ox0 - 1;
             g_n = tl.n; g_co = tl.co0 / BN;
+            // the consumers take the tile's origin from here: decoding it themselves was ~50 scalar instructions per tile
+            // IN the MFMA waves (every instruction of those is additive); all lanes store the same 16 bytes
+            if (pw == 0) *reinterpret_cast<i32x4 *>(tdesc + (k & 1) * 4) = i32x4{tl.n, tl.co0, tl.oy0, tl.ox0};
             g_src1 = a.x1 + (size_t)tl.n * a.C1 * (plane_bytes / 4);
             g_src2 = a.x2 ? a.x2 + (size_t)tl.n * a.C2 * (plane_bytes / 4) : g_src1;
             g_bord = tl.oy0 - 1 < 0 || tl.ox0 - 1 < 0 || tl.oy0 + TH + 1 > a.H || tl.ox0 + TW + 1 > a.W;
@@ -330,6 +344,15 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     *reinterpret_cast<f32x4 *>(xw + xoffp[PLANAR ? j : 0]) = f32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
+            } else if (PLANAR) { // four consecutive columns into the de-interleaved row: one scratch format per instantiation, so
+                                 // that the consumers' patch reads are branch-free (two formats cost them 12 v_mov and a
+                                 // full lgkmcnt wait in front of the first MFMA of every chunk)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float *dst = xw + xoff[j];
+                    dst[0] = d[2 * j][0]; dst[1] = d[2 * j + 1][0];
+                    dst[20] = d[2 * j][1]; dst[21] = d[2 * j + 1][1];
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
@@ -403,33 +426,38 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
     const int lk = lane >> 5, l31 = lane & 31;
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     const int ih = swave & 1, h = swave >> 1;              // which two rows of the transform domain, which cout half
-    const int ty = l31 >> 4, tx = l31 & 15;                // the lane's tile inside the workgroup tile
+    // the lane's tile inside the workgroup tile: row ty, column 2 txh + odd.  The two tiles of a column pair sit 16 lanes
+    // apart (DPP rows r, r + 1), so that the epilogue's exchange of halves is one v_permlane16_swap per register pair
+    const int odd = l31 >> 4, ty = l31 & 1, txh = (l31 & 15) >> 1;
     f32x16 acc[8];
     const int out_plane = a.Ho * a.Wo;
     const int plane4 = out_plane * 4;
-    const int lane_off = (lk * 4 * out_plane + (2 * ty + ih) * a.Wo + 2 * tx) * 4;
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
     float nb = 0.0f;
-    auto fetch_bias = [&](int k) __attribute__((always_inline)) {
-        const TileId t = decode_tile(a, tile_of(k));
-        nb = bload(b_rsrc, lk ? OOB : l31 * 4, (t.co0 + h * 32) * 4);
+    auto fetch_bias = [&](int co0) __attribute__((always_inline)) {
+        nb = bload(b_rsrc, lk ? OOB : l31 * 4, (co0 + h * 32) * 4);
     };
-    if (S > 0 && ih == 0) fetch_bias(0);
+    if (S > 0 && ih == 0) fetch_bias(decode_tile(a, tile_of(0)).co0);
+    const float sgn = ih == 0 ? 1.0f : -1.0f;
     // R / W2 (the consumers' share of the window): wave w transforms the (tile, channel) pairs of producer wave w's
     // scratch -- lane map 16 tiles x 2 k-steps x 2 channel parities, so that the 32 lanes of an LDS store group write a
     // 64-float span of the [tile][k-step] image at most 2-way conflicted (free)
     const int w_t16 = lane & 15, w_kpl = (lane >> 4) & 1;
     const float *const xr0 = lds + 2 * STAGE + XCH_FLOATS + STAT_FLOATS + swave * XWAVE + ((2 * w_kpl + lk) * 4) * XP + 2 * w_t16;
-    const int v_lane = (lk * 32 + 16 * (swave & 1) + w_t16) * 4 + 2 * (swave >> 1) + w_kpl;      // + xi * 256 (+ stage)
+    const int v_slot = (w_t16 & 1) * 16 + (w_t16 >> 1) * 2 + (swave & 1);           // MFMA lane of tile (row swave & 1, column w_t16)
+    const int v_lane = (lk * 32 + v_slot) * 4 + 2 * (swave >> 1) + w_kpl;                        // + xi * 256 (+ stage)
     float patch[16];
-    auto read_patch = [&](bool planar, int par) __attribute__((always_inline)) {
+    // (PLANAR instantiation: every scratch row is [even window columns: 20][odd: 20]; the patch registers keep the order the
+    //  two ds_read2_b32 of a row deliver -- columns 0, 2, 1, 3 -- and W2 indexes them through pcol)
+    constexpr int pcol[4] = {0, PLANAR ? 2 : 1, PLANAR ? 1 : 2, 3};                  // register position of patch column c
+    auto read_patch = [&](int par) __attribute__((always_inline)) {
         const float *const xr = xr0 + par * (4 * XWAVE);                            // the scratch half of the chunk's parity
-        const float *const xrp = xr - w_t16;                // planar chunks: [even window columns: 20][odd: 20], column pair t16, t16 + 1
-        if (PLANAR && planar) {      // (uniform)
+        const float *const xrp = xr - w_t16;                                        // column pairs (t16, t16 + 1) of both halves
+        if (PLANAR) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                patch[4 * r] = xrp[r * XP]; patch[4 * r + 2] = xrp[r * XP + 1];
-                patch[4 * r + 1] = xrp[r * XP + 20]; patch[4 * r + 3] = xrp[r * XP + 21];
+                patch[4 * r] = xrp[r * XP]; patch[4 * r + 1] = xrp[r * XP + 1];
+                patch[4 * r + 2] = xrp[r * XP + 20]; patch[4 * r + 3] = xrp[r * XP + 21];
             }
         } else {
 #pragma unroll
@@ -447,13 +475,17 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
     unsigned long long t_mma = 0, t_epi = 0, t_bar = 0;
     const unsigned long long t_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long t_last = t_begin;
-    int k = 0, ch = -1;                                    // running (tile, chunk in tile): no division in the MFMA wave
     if (S > 0) {
         __syncthreads();                                   // P: the producers' prologue has put X(0) into the scratch
-        read_patch(PLANAR, 0);                             // (chunk 0 is x1's)
+        read_patch(0);
     }
-    for (int s = 0; s < S; ++s) {
-        if (++ch == nchunks) { ch = 0; ++k; }
+    // One chunk: W2(s), hand-over, R(s + 1), the 32 MFMAs.  The first chunk of a tile STARTS its accumulators (C = 0 in the
+    // first MFMA of each) instead of clearing them beforehand, and the tile loop below peels it: cleared under `if (ch == 0)`
+    // inside one flat chunk loop the 128 accumulator registers were a loop-carried value the compiler could not see dying,
+    // i.e. live through the whole epilogue -- no room to have the tile's residual loads in flight together (and 128 v_mov
+    // per tile in the MFMA waves).
+    int s = 0;                                             // running chunk index (stage / scratch parity): no division in the MFMA wave
+    auto chunk = [&](auto first, int ch) __attribute__((always_inline)) {
         {
             // W2(s): B^T d B of the lane's 4x4 patch (read from the producers' scratch one chunk ago, beside the MFMAs)
             float tt[16];
@@ -467,146 +499,178 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             float *vdst = lds + (s & 1) * STAGE + v_lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                vdst[(i * 4 + 0) * 256] = tt[i * 4 + 0] - tt[i * 4 + 2];
-                vdst[(i * 4 + 1) * 256] = tt[i * 4 + 1] + tt[i * 4 + 2];
-                vdst[(i * 4 + 2) * 256] = tt[i * 4 + 2] - tt[i * 4 + 1];
-                vdst[(i * 4 + 3) * 256] = tt[i * 4 + 1] - tt[i * 4 + 3];
+                const int rs = row_slot(i);
+                vdst[(rs * 4 + 0) * 256] = tt[i * 4 + pcol[0]] - tt[i * 4 + pcol[2]];
+                vdst[(rs * 4 + 1) * 256] = tt[i * 4 + pcol[1]] + tt[i * 4 + pcol[2]];
+                vdst[(rs * 4 + 2) * 256] = tt[i * 4 + pcol[2]] - tt[i * 4 + pcol[1]];
+                vdst[(rs * 4 + 3) * 256] = tt[i * 4 + pcol[1]] - tt[i * 4 + pcol[3]];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                   // hand-over: stage (s&1) is complete
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < S) read_patch(PLANAR && (ch + 1 == nchunks ? 0 : ch + 1) * KC < a.C1, (s + 1) & 1);      // R(s+1): used after the MFMAs
-        if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_bar += now - t_last; t_last = now; }
-        if (ch == 0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[e][r] = 0.0f;
-        }
         const float *stage = lds + (s & 1) * STAGE;
         {
+            constexpr bool FIRST = decltype(first)::value;
+            // the operands of the first two positions first: the LDS returns in order, and behind the patch reads of R(s+1) the
+            // first MFMA of every chunk started ~200 cycles later
             f32x4 a_c = *reinterpret_cast<const f32x4 *>(stage + a_off), b_c = *reinterpret_cast<const f32x4 *>(stage + b_off), a_n, b_n;
+            if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_bar += now - t_last; t_last = now; }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (e + 1 < 8) {
                     a_n = *reinterpret_cast<const f32x4 *>(stage + a_off + (e + 1) * 512);
                     b_n = *reinterpret_cast<const f32x4 *>(stage + b_off + (e + 1) * 256);
                 }
+                if (e == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    // R(s+1), used after the MFMAs (unconditional: past the last chunk it reads stale scratch, unused -- under
+                    // `if (s + 1 < S)` the waitcnt in front of the first MFMA has to assume the path without these reads)
+                    read_patch((s + 1) & 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
+                if (FIRST) {
+                    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[0], b_c[0], zero, 0, 0, 0);
+                } else {
+                    acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[0], b_c[0], acc[e], 0, 0, 0);
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[q], b_c[q], acc[e], 0, 0, 0);
+                for (int q = 1; q < 4; ++q) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[q], b_c[q], acc[e], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (e + 1 < 8) { a_c = a_n; b_c = b_n; }
             }
         }
         if (stamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_mma += now - t_last; t_last = now; }
-        if (ch != nchunks - 1) continue;
+        ++s;
+    };
+    for (int k = 0; k < n_my; ++k) {
+        chunk(std::true_type{}, 0);
+        for (int ch = 1; ch < nchunks; ++ch) chunk(std::false_type{}, ch);
         // ---------------------------------------------------------------- tile epilogue
         if (estamp) e_t = __builtin_amdgcn_s_memtime();
+        // the tile's origin, published by the producers when they described it (two chunks before its first load)
+        const i32x4 td = *reinterpret_cast<const i32x4 *>(tdesc + (k & 1) * 4);
         // + bias through position (1, 1) (accumulator 5 of the ih = 0 waves), whose output coefficients are all 1
         if (ih == 0) {
             acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb, 1.0f, acc[5], 0, 0, 0);
-            if (k + 1 < n_my) fetch_bias(k + 1);
+            if (k + 1 < n_my) fetch_bias(__builtin_amdgcn_readfirstlane(tdesc[((k + 1) & 1) * 4 + 1]));
         }
-        const TileId t = decode_tile(a, tile_of(k));
-        // columns first (in-lane): T_i[b] = sum_j M[i][j] A[j][b],  A^T = [[1,1,1,0],[0,1,-1,-1]]
-        // then the wave's own two rows: ih = 0 keeps P = T0 + T1 (output row 0) and sends T1; ih = 1 keeps R = T2 + T3
-        // (output row 1 = T1 - R) and sends T2
-        float keep[16][2];
-        {
-            float *xw = xch + (swave * 8) * 256 + lane * 4;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x4 snd;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float m0 = acc[0][r + u], m1 = acc[1][r + u], m2 = acc[2][r + u], m3 = acc[3][r + u];
-                    const float n0 = acc[4][r + u], n1 = acc[5][r + u], n2 = acc[6][r + u], n3 = acc[7][r + u];
-                    const float lo0 = (m0 + m1) + m2, lo1 = (m1 - m2) - m3;      // first of the wave's rows (i = 2 ih)
-                    const float hi0 = (n0 + n1) + n2, hi1 = (n1 - n2) - n3;      // second (i = 2 ih + 1)
-                    keep[r + u][0] = lo0 + hi0;
-                    keep[r + u][1] = lo1 + hi1;
-                    snd[2 * u] = ih == 0 ? hi0 : lo0;                            // T1 from ih = 0, T2 from ih = 1
-                    snd[2 * u + 1] = ih == 0 ? hi1 : lo1;
-                }
-                *reinterpret_cast<f32x4 *>(xw + (r >> 1) * 256) = snd;
-            }
-        }
-        if (estamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); e_p1 += now - e_t; e_t = now; }
-        __syncthreads();                                   // E: both halves of every (tile, cout) are in LDS
-        if (estamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); e_wait += now - e_t; e_t = now; }
+        TileId t;
+        t.n = __builtin_amdgcn_readfirstlane(td[0]); t.co0 = __builtin_amdgcn_readfirstlane(td[1]);
+        t.oy0 = __builtin_amdgcn_readfirstlane(td[2]); t.ox0 = __builtin_amdgcn_readfirstlane(td[3]);
         const size_t sample = (size_t)t.n * a.Cout * out_plane;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * out_plane * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0, a.Cout * out_plane * 4, 0x00020000);
-        // Two neighbouring lanes (tile columns 2m, 2m + 1) hold 4 consecutive pixels of the row between them.  Registers are
-        // taken in pairs (couts c, c + 1): the lanes swap one half each (DPP quad_perm [1,0,3,2]), after which the even lane
-        // owns the 4 pixels of cout c and the odd lane those of cout c + 1 -- 16-byte stores and residual loads, half as
+        // (no residual: zero records -- the loads below return 0 and the add stays unconditional; as a select on the uniform
+        //  a.res it was four v_cndmask per pair)
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0,
+                                                                                   a.res ? a.Cout * out_plane * 4 : 0, 0x00020000);
+        // The lanes l and l + 16 (tile columns 2m, 2m + 1) hold 4 consecutive pixels of the row between them.  Registers are
+        // taken in pairs (couts c, c + 1): v_permlane16_swap exchanges one half each, after which the lane of the even column
+        // owns the 4 pixels of cout c and the other one those of cout c + 1 -- 16-byte stores and residual loads, half as
         // many memory instructions (the store path retires about one instruction per 100 cycles and wave whatever its width:
         // with 8-byte stores this phase took 5.3k cycles per tile without residual, 11.7k with residual and statistics), and
         // the statistics need 3 DPP steps per pair instead of 4 per register.
-        const int odd = tx & 1;
-        const int py = t.oy0 + 2 * ty + ih, px4 = t.ox0 + 4 * (tx >> 1);
+        const int py = t.oy0 + 2 * ty + ih, px4 = t.ox0 + 4 * txh;
         const bool rok = py < a.Ho;
-        const int lane_off4 = ((lk * 4 + odd) * out_plane + (2 * ty + ih) * a.Wo + 4 * (tx >> 1)) * 4;
+        const int lane_off4 = ((lk * 4 + odd) * out_plane + (2 * ty + ih) * a.Wo + 4 * txh) * 4;
         const int voff4 = (rok && px4 + 3 < a.Wo) ? lane_off4 : OOB;             // all four pixels of the lane's run
         const bool ragged = t.ox0 + TW > a.Wo && (a.Wo & 3) != 0;                // (wave-uniform) a run straddles the right edge
+        const bool clipped = t.oy0 + TH > a.Ho || t.ox0 + TW > a.Wo;             // (wave-uniform) some lanes own no pixels
         const int nval = a.Wo - px4;                                              // ... then it has 1..3 pixels
         const bool part = ragged && rok && nval > 0 && nval < 4;
         const int so0 = ((t.co0 + h * 32) * out_plane + min(t.oy0, a.Ho - 1) * a.Wo + t.ox0) * 4;
         const float *xr2 = xch + ((swave ^ 1) * 8) * 256 + lane * 4;
         float *sb = stat_lds + swave * 128;
-#define IPDM_SWAP1(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0xB1, 0xf, 0xf, false))
-#define IPDM_ROR(v, c) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (c), 0xf, 0xf, false))
+        const f32x2 sgn2 = {sgn, sgn};
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        f32x4 rv[2];
-        auto load_res = [&](int i, f32x4 &dst) __attribute__((always_inline)) {      // pair i: registers 2 i, 2 i + 1
-            const int so = so0 + (8 * (i >> 1) + 2 * (i & 1)) * plane4;
-            dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4, so, 0));
-        };
-        if (a.res) load_res(0, rv[0]);
-        f32x4 got = {0, 0, 0, 0};
+        // ALL residual loads of the tile are issued together, ahead of the transform: issued one pair ahead inside the store
+        // loop, every pair waited a full memory latency (and, vmcnt counting in order, for the stores in between) -- 6.0k of
+        // the epilogue's 7.5k cycles per tile (stamps)
+        f32x4 rv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4, so0 + (8 * (i >> 1) + 2 * (i & 1)) * plane4, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        // columns first (in-lane): T_i[b] = sum_j M[i][j] A[j][b],  A^T = [[1,1,1,0],[0,1,-1,-1]]; then the wave's own two
+        // rows (first = accumulators 0-3, second = 4-7; ih = 0: rows 0, 1, ih = 1: rows 3, 2 -- row_slot): both waves keep
+        // K = first + second and send the second (T1 resp. T2); output row 0 = (T0 + T1) + T2, row 1 = T1 - (T2 + T3).
+        // Register pairs (r, r + 1) = couts (c, c + 1) as packed-f32 operations: half the instructions.
+        f32x2 K0[8], K1[8];                                 // [pair]: output column 0 / 1 of {cout c, cout c + 1}
+        {
+            float *xw = xch + (swave * 8) * 256 + lane * 4;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int r = 2 * p;
+#define IPDM_M(e) f32x2{acc[e][r], acc[e][r + 1]}
+                const f32x2 lo0 = (IPDM_M(0) + IPDM_M(1)) + IPDM_M(2), lo1 = (IPDM_M(1) - IPDM_M(2)) - IPDM_M(3);
+                const f32x2 hi0 = (IPDM_M(4) + IPDM_M(5)) + IPDM_M(6), hi1 = (IPDM_M(5) - IPDM_M(6)) - IPDM_M(7);
+#undef IPDM_M
+                K0[p] = lo0 + hi0;
+                K1[p] = lo1 + hi1;
+                *reinterpret_cast<f32x4 *>(xw + p * 256) = f32x4{hi0[0], hi0[1], hi1[0], hi1[1]};
+            }
+        }
+        if (estamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); e_p1 += now - e_t; e_t = now; }
+        __syncthreads();                                   // E: both halves of every (tile, cout) are in LDS
+        if (estamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); e_wait += now - e_t; e_t = now; }
+        f32x4 gotv[8];                                     // partner's {T[0] c, T[0] c+1, T[1] c, T[1] c+1} of every pair: one LDS latency
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gotv[i] = *reinterpret_cast<const f32x4 *>(xr2 + i * 256);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int g = i >> 1, u = 2 * (i & 1), r = 4 * g + u;
-            if (a.res && i + 1 < 8) load_res(i + 1, rv[(i + 1) & 1]);
-            got = *reinterpret_cast<const f32x4 *>(xr2 + i * 256);                     // partner's {T(r)[0], T(r)[1], T(r+1)[0], T(r+1)[1]}
-            // output row 0 = (T0 + T1) + T2;  output row 1 = T1 - (T2 + T3)
-            const float ya0 = ih == 0 ? keep[r][0] + got[0] : got[0] - keep[r][0], ya1 = ih == 0 ? keep[r][1] + got[1] : got[1] - keep[r][1];
-            const float yb0 = ih == 0 ? keep[r + 1][0] + got[2] : got[2] - keep[r + 1][0], yb1 = ih == 0 ? keep[r + 1][1] + got[3] : got[3] - keep[r + 1][1];
-            // (scalars on purpose: with the halves as 2-vectors and vector selects the compiler folded the two DPP moves
-            //  into one and every lane received the first component twice)
-            const float give0 = odd ? ya0 : yb0, give1 = odd ? ya1 : yb1;
-            const float recv0 = IPDM_SWAP1(give0), recv1 = IPDM_SWAP1(give1);
-            f32x4 v;
-            v[0] = odd ? recv0 : ya0; v[1] = odd ? recv1 : ya1; v[2] = odd ? yb0 : recv0; v[3] = odd ? yb1 : recv1;
+            const int g = i >> 1, u = 2 * (i & 1);
+            const f32x4 got = gotv[i];
+            // ih = 0: K + T2 (output row 0);  ih = 1: T1 - K (output row 1)
+            const f32x2 y0 = __builtin_elementwise_fma(K0[i], sgn2, f32x2{got[0], got[1]});       // column 0 of {cout c, c + 1}
+            const f32x2 y1 = __builtin_elementwise_fma(K1[i], sgn2, f32x2{got[2], got[3]});       // column 1
+            // rows r (even tile column) and r + 1 (odd) of the DPP row pair: the even one gives its cout c + 1 and takes the
+            // odd one's cout c
+            // (inline asm: through the builtin, with the halves of the 2-vectors as operands, this compiler passed component 0
+            //  of y0 / y1 as BOTH operands of the swap; s_nop: the swap reads need two wait states after the VALU writes)
+            float ya0 = y0[0], yb0 = y0[1], ya1 = y1[0], yb1 = y1[1];
+            asm("s_nop 1\n\t"
+                "v_permlane16_swap_b32 %0, %1\n\t"
+                "v_permlane16_swap_b32 %2, %3"
+                : "+v"(ya0), "+v"(yb0), "+v"(ya1), "+v"(yb1));
+            f32x4 v = {ya0, ya1, yb0, yb1};
             const int so = so0 + (8 * g + u) * plane4;
-            if (a.res) v += rv[i & 1];
+            v += rv[i];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4, so, 0);
             if (ragged) {            // (wave-uniform) the run that straddles the edge: element by element, by its lane
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int vo1 = (part && e < nval) ? lane_off4 + 4 * e : OOB;
                     float x = v[e];
-                    if (a.res) x += bload(r_rsrc, vo1, so);
+                    if (a.res) x += bload(r_rsrc, vo1, so);        // (the lane's 16-byte residual load was out of range: + 0 above)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), o_rsrc, vo1, so, 0);
                     if (part) v[e] = e < nval ? x : 0.0f;
                 }
             }
             if (a.stats) {
                 // fused GroupNorm statistics of the output: one row of per-cout {sum, sum of squares} per PIXEL ROW and
-                // 32-pixel column block, as conv_ws.hip writes them; the 8 lanes of one parity in a DPP row share a cout
-                const bool ok = voff4 != OOB || part;
-                float s1 = ok ? (v[0] + v[1]) + (v[2] + v[3]) : 0.0f;
-                float s2 = ok ? fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0]))) : 0.0f;
-                s1 += IPDM_ROR(s1, 0x122); s2 += IPDM_ROR(s2, 0x122);              // row_ror:2, 4, 8: lanes of the same parity
-                s1 += IPDM_ROR(s1, 0x124); s2 += IPDM_ROR(s2, 0x124);
-                s1 += IPDM_ROR(s1, 0x128); s2 += IPDM_ROR(s2, 0x128);
-                if (tx < 2) *reinterpret_cast<f32x2 *>(sb + (ty * 32 + 8 * g + u + tx + 4 * lk) * 2) = f32x2{s1, s2};
+                // 32-pixel column block, as conv_ws.hip writes them; the 8 lanes of one tile row in a DPP row share a cout
+                float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                float s2 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                if (clipped) {
+                    const bool ok = voff4 != OOB || part;
+                    s1 = ok ? s1 : 0.0f; s2 = ok ? s2 : 0.0f;
+                }
+                // row_ror:2, 4, 8 with the DPP operand on the add itself (as update_dpp + add the compiler emits a zeroing
+                // move, a DPP move and an add per step); s_nop: a DPP read needs two wait states after the VALU write
+                asm("s_nop 1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                    "s_nop 0\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                    "s_nop 0\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf"
+                    : "+v"(s1), "+v"(s2));
+                if (txh == 0) *reinterpret_cast<f32x2 *>(sb + (ty * 32 + 8 * g + u + odd + 4 * lk) * 2) = f32x2{s1, s2};
             }
         }
-#undef IPDM_SWAP1
-#undef IPDM_ROR
         if (estamp) { const unsigned long long now = __builtin_amdgcn_s_memtime(); e_p2 += now - e_t; e_t = now; }
         if (a.stats) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -654,7 +718,7 @@ bool conv_wino_shape_ok(int Cout, int Cin, int ks, int stride, int interleave)
     return ks == 3 && stride == 1 && (interleave == 2 || interleave == 4) && Cout % BN == 0 && Cin % KC == 0 && Cin >= 32;
 }
 
-// [chunk q][cout tile][xi][h][lk][cout 32][kp]: U = G g G^T in double, rounded once; channel = 8 q + 2 kp + lk
+// [chunk q][cout tile][xi][h][lk][cout 32][kp], xi = row_slot(i) * 4 + j: U = G g G^T in double, rounded once; channel = 8 q + 2 kp + lk
 void conv_pack_weights_wino(const float *w, int Cout, int Cin, std::vector<float> &packed)
 {
     const int nq = (Cin + KC - 1) / KC, nct = Cout / BN;
@@ -671,7 +735,7 @@ void conv_pack_weights_wino(const float *w, int Cout, int Cin, std::vector<float
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) {
                     const double u = gg[i][0] * G[j][0] + gg[i][1] * G[j][1] + gg[i][2] * G[j][2];
-                    base[(((((i * 4 + j) * 2 + hh) * 2 + lk) * 32 + cl) * 4) + kp] = (float)u;
+                    base[(((((row_slot(i) * 4 + j) * 2 + hh) * 2 + lk) * 32 + cl) * 4) + kp] = (float)u;
                 }
         }
 }
