@@ -46,6 +46,7 @@ enum Opt {
     OPT_CONV_LEGACY, OPT_CONV1X1_LEGACY, OPT_CONVS2_LEGACY,      // route kernel families to the round-1 4-wave kernels
     OPT_CONV_NO_DIRECT, OPT_DIRECT_NO_PLANAR, OPT_DIRECT_MAX_CIN, OPT_DIRECT_NO_S2,
     OPT_CONV_SX_CW2, OPT_CONV_DBG, OPT_CONV_VEC4_STRICT, OPT_CONV_NO_SPLITK, OPT_CONV_NO_WINO, OPT_CONV1X1_NO_QUARTER,
+    OPT_CONV_NM,             // opt-in: narrow stride-1 layers on the 16-cout MFMA (conv_nm.hip): 1 = 16-cout layers, 2 = 8-cout too
     OPT_GN_TWO_STAGE, OPT_GN_UNFUSED,
     OPT_UNET_TRANSPOSE,      // -1 automatic | 0 never | 1 always
     OPT_ATTN_NO_KVSPLIT, OPT_ATTN_LEGACY, OPT_ATTN_NO_ZSEQ,

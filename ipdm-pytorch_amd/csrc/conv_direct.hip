@@ -396,6 +396,7 @@ int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
     IPDM_REQUIRE(!a.x1_planar || (!a.upsample && !(a.Hs & 1) && !(a.Ws & 1)), "conv2d: parity-planar input of odd size %dx%d", a.Hs, a.Ws);
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29),
                  "conv2d: per-sample tensor exceeds the 2 GiB buffer-addressing range");
+    if (conv_nm_eligible(a)) return conv2d_nm_launch(a, st);      // same tiles, same statistics rows: interchangeable
     if (a.stride == 2) {
         if (a.Cout <= 4) return launch_direct_s2<4>(a, st);
         if (a.Cout <= 8) return launch_direct_s2<8>(a, st);

@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
                     *reinterpret_cast<f32x4 *>(xw + xoff[j]) = f32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
             }
         };
-        const bool pstamp = IPDM_CONV_STAMPS && (a.dbg & 8) != 0;
+        const bool pstamp = IPDM_CONV_STAMPS && (a.dbg & 8) != 0 && !(a.dbg & 32);      // (32: consumer stamps only -- the producers' perturb more)
         unsigned long long p_issue = 0, p_wait = 0, p_math = 0, p_hand = 0, p_t = 0;
         // one step: on entry  w(s) is in `wc` (issued one step ago), raw(s+1) in `rc` (issued one step ago), patch(s) in
         // registers; the step issues w(s+1) -> `wn` and raw(s+2) -> `rn`
@@ -748,7 +748,7 @@ int conv2d_wino_launch(const ConvArgs &args, hipStream_t st)
     a.tiles_y = cdiv(a.Ho, TH);
     a.co_tiles = a.Cout / BN;
     a.ksplit = 1;
-    a.dbg = a.dbg_buf ? (opt(OPT_CONV_DBG) & 24) : 0;
+    a.dbg = a.dbg_buf ? (opt(OPT_CONV_DBG) & 56) : 0;
     IPDM_REQUIRE(conv_wino_eligible(args), "conv2d_wino: layer not eligible");
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29) &&
                      (long)a.Cout * a.Ho * a.Wo < (1L << 29) && (long)(a.C1 + a.C2) / KC * a.co_tiles * U_CHUNK_FLOATS < (1L << 29),

@@ -59,6 +59,8 @@ void conv_sx_pack_weights(const float *w, int Cout, int Cin, int ns, std::vector
 int conv2d_sx_launch(const ConvArgs &a, hipStream_t st);
 bool conv_direct_eligible(const ConvArgs &a);             // narrow layers: direct packed-f32 VALU kernel (conv_direct.hip)
 int conv2d_direct_launch(const ConvArgs &a, hipStream_t st);
+bool conv_nm_eligible(const ConvArgs &a);                 // ... of those, the stride-1 layers that run on the 16-cout MFMA (conv_nm.hip)
+int conv2d_nm_launch(const ConvArgs &a, hipStream_t st);
 int conv_k_chunk();   // concat inputs must split at a multiple of this many channels (3x3 kernels)
 int conv_ws_k_chunk(int ks, int interleave);   // K chunk of the kernel a (ks, weight layout) pair runs on: also its concat alignment
 

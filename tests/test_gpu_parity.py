@@ -556,6 +556,31 @@ def test_fused_groupnorm_statistics_chain(case):
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
 
 
+def test_narrow_convolutions_on_the_16_cout_mfma_opt_in():
+    """conv_nm.hip (option conv_nm, off by default: DESIGN 6, negative results): the narrow stride-1 layers on
+    v_mfma_f32_16x16x4_f32 -- single convolutions (3x3 / 1x1, 8 and 16 couts, concat, every channel-group count, ragged
+    strips, widths that are not multiples of 4, all prologues, residual) and the fused-statistics chain -- against the
+    same torch references and tolerance as the default kernels."""
+    from ipdm_pytorch_amd import _lib
+    with _lib.option("conv_nm", 2):
+        for i, case in enumerate([
+                # B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res
+                (1, 8, 0, 16, 64, 16, 64, 8, 3, 1, 0, False),
+                (2, 16, 0, 37, 45, 37, 45, 16, 3, 1, 2, True),        # ragged both ways, element-wise stores
+                (1, 16, 0, 50, 200, 50, 200, 16, 3, 1, 2, True),      # several strips, W % 64 != 0
+                (2, 8, 4, 33, 132, 33, 132, 8, 3, 1, 2, False),       # concat 8 + 4 (3 groups)
+                (1, 16, 16, 70, 128, 70, 128, 16, 3, 1, 2, False),    # 8 groups
+                (1, 16, 8, 64, 192, 64, 192, 8, 3, 1, 1, False),      # 6 groups, GroupNorm without SiLU
+                (1, 4, 0, 40, 72, 40, 72, 8, 3, 1, 2, False),         # one group
+                (1, 8, 0, 20, 68, 20, 68, 16, 3, 1, 2, False),
+                (2, 16, 8, 35, 140, 35, 140, 8, 1, 1, 0, False),      # 1x1 shortcuts
+                (1, 16, 0, 47, 61, 47, 61, 16, 1, 1, 0, True)]):
+            _conv_case(*case, seed=7000 + i)
+        for case in [(2, 16, 70, 200, 16, 3, 1, True, 2, 16), (1, 16, 37, 130, 16, 3, 1, False, 2, 16),
+                     (2, 8, 70, 200, 8, 3, 1, True, 2, 8), (1, 8, 33, 61, 16, 1, 1, False, 1, 16)]:
+            test_fused_groupnorm_statistics_chain(case)
+
+
 @pytest.mark.parametrize("offset", [30.0, 300.0])
 def test_fused_groupnorm_statistics_with_a_large_channel_offset(offset):
     """Fused statistics are float32 per-tile {sum, sum of squares} folded in float64 (var = E[v^2] - mean^2).  With a
