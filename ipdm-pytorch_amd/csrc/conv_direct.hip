@@ -33,10 +33,32 @@ namespace {
 // output element once
 inline double direct_bytes(const ConvArgs &a)
 {
-    return 4.0 * a.B * ((double)(a.C1 + a.C2) * a.Hs * a.Ws + (double)a.Cout * a.Ho * a.Wo * (a.res ? 2 : 1));
+    return 4.0 * a.B * ((double)(a.C1 + a.C2 + (a.sk_w ? a.sk_C1 + a.sk_C2 : 0)) * a.Hs * a.Ws + (double)a.Cout * a.Ho * a.Wo * (a.res ? 2 : 1));
 }
 
 constexpr int DT_W = 64, DT_H = 16;
+
+// Which tile a workgroup takes.  Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), so with
+// tile = blockIdx the horizontal and vertical neighbours of every tile run on OTHER XCDs and each XCD's L2 fetches the
+// halo columns and rows again: a 64-pixel row segment with its two halo pixels touches four 128-byte lines, two of them
+// for one pixel each (rocprofv3 FETCH_SIZE of the 8 -> 8 layer: 1.5x its algorithmic reads, and the kernel sits at 5.3 TB/s
+// of REAL traffic -- profiles/r03b_hbm_by_kernel.csv).  Here XCD x takes the x-th contiguous eighth of the tile sequence in
+// row-major order, so neighbouring tiles share an L2 and run close in time.  A bijection for any grid size.
+struct DTile { int bx, by, n; };
+__device__ inline DTile direct_tile()
+{
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy * gridDim.z;
+    const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
+    const int t = xcd * q + min(xcd, r) + idx;
+    DTile d;
+    d.bx = t % gx;
+    const int rest = t / gx;
+    d.by = rest % gy;
+    d.n = rest / gy;
+    return d;
+}
 constexpr int DIN_P1 = 68;     // LDS row pitch at stride 1: 16-byte aligned runs of 4 (+ halo); stride 2: 132
 
 // 16-lane sums: DPP row rotations; every lane of the row ends with the total
@@ -115,7 +137,7 @@ __device__ inline void direct_epilogue(const ConvArgs &a, f32x2 (&acc)[4][CO / 2
                           (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
                 s = sum_lanes_row(s);
                 if (j == 0) {
-                    const int row = blockIdx.y * gridDim.x + blockIdx.x;
+                    const int row = (oy0 / DT_H) * gridDim.x + ox0 / DT_W;
                     a.stats[(((size_t)n * a.stats_rows + row) * a.Cout + (k >> 1)) * 2 + (k & 1)] = s;
                 }
             }
@@ -129,9 +151,14 @@ __device__ inline void direct_epilogue(const ConvArgs &a, f32x2 (&acc)[4][CO / 2
 // when the statistics epilogue is compiled in: this loop lives on occupancy)
 // PLANAR: x1 is stored parity-planar (ConvArgs::x1_planar: the output of an up-sampling convolution in its parity form)
 // STRIDE 2 (Downsample of the narrow levels, 3x3): the same 64x16 OUTPUT tile over a 33 x 129 input window, 2 channels per pass
-template <int CO, int KS, int DKC, bool PLANAR, int STRIDE = 1>
+// SKIP (1: NCHW, 2: its x1 parity-planar): the ResidualBlock's 1x1 shortcut over the block input (Model/model.py:116-130,
+// ConvArgs::sk_*) as EXTRA K chunks of this (the block's second) 3x3 convolution -- centre tap only, no prologue, into the same
+// accumulators.  The shortcut's launch, the write of its output and the read of that output as this layer's residual
+// disappear: 2 * Cout * 4 bytes per pixel of a family that runs at 5.3 TB/s of real HBM traffic.
+template <int CO, int KS, int DKC, bool PLANAR, int STRIDE = 1, int SKIP = 0>
 __global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3)))) conv_direct_kernel(ConvArgs a)
 {
+    static_assert(SKIP == 0 || (KS == 3 && STRIDE == 1 && !PLANAR), "conv_direct: the fused shortcut rides on a 3x3 stride-1 NCHW layer");
     constexpr int DIN_H = (DT_H - 1) * STRIDE + KS, DIN_W = (DT_W - 1) * STRIDE + KS, DIN_P = STRIDE == 1 ? DIN_P1 : 132;
     constexpr int DIN_CH = DIN_H * DIN_P, TAPS = KS * KS, PAD = KS / 2;
     static_assert(STRIDE == 1 || (KS == 3 && !PLANAR), "conv_direct: stride 2 is the 3x3 Downsample");
@@ -144,8 +171,9 @@ __global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <=
     cfloat *gsc = (cfloat *)(unsigned long long)a.gn_scale, *gsh = (cfloat *)(unsigned long long)a.gn_shift;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    const int n = blockIdx.z;
-    const int ox0 = blockIdx.x * DT_W, oy0 = blockIdx.y * DT_H;
+    const DTile dt = direct_tile();
+    const int n = dt.n;
+    const int ox0 = dt.bx * DT_W, oy0 = dt.by * DT_H;
     const int Ctot = a.C1 + a.C2;
     const int src_plane = a.Hs * a.Ws;
 
@@ -172,7 +200,7 @@ __global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <=
         }
         // byte offsets inside a channel plane (buffer loads: no 64-bit address arithmetic on the VALU, which bounds this kernel)
         sp_src[j] = e < DIN_H * DIN_W ? (sy * a.Ws + sx) * 4 : DOOB;
-        sp_srcp[j] = !PLANAR ? sp_src[j]
+        sp_srcp[j] = !(PLANAR || SKIP == 2) ? sp_src[j]
                    : (e < DIN_H * DIN_W ? ((((sy & 1) * 2 + (sx & 1)) * (a.Hs >> 1) + (sy >> 1)) * (a.Ws >> 1) + (sx >> 1)) * 4 : DOOB);
         sp_dst[j] = e < DIN_H * DIN_W ? r * DIN_P + c : -1;
     }
@@ -180,21 +208,33 @@ __global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <=
     const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.x1 + (size_t)n * a.C1 * src_plane), 0, a.C1 * plane_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.x2 ? a.x2 + (size_t)n * a.C2 * src_plane : a.x1), 0, a.x2 ? a.C2 * plane_bytes : 0, 0x00020000);
 
-    for (int c0 = 0; c0 < Ctot; c0 += DKC) {
-        const int kc = min(DKC, Ctot - c0);
+    // one pass over the channels of a source pair: the layer's own input (all taps, fused prologue), or the block input of
+    // the fused shortcut (SK: centre tap, raw values)
+    auto run_chunks = [&](auto sk_tag) __attribute__((always_inline)) {
+    constexpr bool SK = decltype(sk_tag)::value;
+    const int C1v = SK ? a.sk_C1 : a.C1, Ctotv = SK ? a.sk_C1 + a.sk_C2 : Ctot;
+    const int actv = SK ? 0 : a.act;
+    const __amdgpu_buffer_rsrc_t rsA = SK ? __builtin_amdgcn_make_buffer_rsrc((void *)(a.sk_x1 + (size_t)n * a.sk_C1 * src_plane), 0, a.sk_C1 * plane_bytes, 0x00020000) : rsrc1;
+    const __amdgpu_buffer_rsrc_t rsB = SK ? __builtin_amdgcn_make_buffer_rsrc((void *)(a.sk_x2 ? a.sk_x2 + (size_t)n * a.sk_C2 * src_plane : a.sk_x1), 0,
+                                                                               a.sk_x2 ? a.sk_C2 * plane_bytes : 0, 0x00020000) : rsrc2;
+    constexpr bool PL = SK ? SKIP == 2 : PLANAR;
+    cfloat *wkv = SK ? (cfloat *)(unsigned long long)a.sk_w : wk;
+    const int cpadv = SK ? a.sk_cout_pad : a.cout_pad;
+    for (int c0 = 0; c0 < Ctotv; c0 += DKC) {
+        const int kc = min(DKC, Ctotv - c0);
         __syncthreads();                                   // previous chunk fully consumed
         // all global loads of the chunk first (one latency), then the transform
         float raw[DKC][NSP];
 #pragma unroll
         for (int c = 0; c < DKC; ++c) {
-            const int cg = min(c0 + c, Ctot - 1);          // channels beyond Cin re-read the last one; they are not consumed
+            const int cg = min(c0 + c, Ctotv - 1);         // channels beyond Cin re-read the last one; they are not consumed
             // (no branch around the loads: all loads of the chunk must issue back to back; the source is picked by scalar
             //  selects, and only a parity-planar x1 costs a per-load select of the offset)
-            const bool from1 = cg < a.C1;
-            const __amdgpu_buffer_rsrc_t r = from1 ? rsrc1 : rsrc2;
-            const int so = (from1 ? cg : cg - a.C1) * plane_bytes;
+            const bool from1 = cg < C1v;
+            const __amdgpu_buffer_rsrc_t r = from1 ? rsA : rsB;
+            const int so = (from1 ? cg : cg - C1v) * plane_bytes;
 #pragma unroll
-            for (int j = 0; j < NSP; ++j) raw[c][j] = dload(r, PLANAR && from1 ? sp_srcp[j] : sp_src[j], so);
+            for (int j = 0; j < NSP; ++j) raw[c][j] = dload(r, PL && from1 ? sp_srcp[j] : sp_src[j], so);
         }
 #pragma unroll
         for (int c = 0; c < DKC; ++c) {
@@ -202,16 +242,16 @@ __global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <=
                 float sc = 1.0f, sh = 0.0f;
                 // (constant address space: scalar loads.  As vector loads they sit behind the chunk's 40 tile loads in the
                 //  in-order memory counter and every channel's transform waits for all of them)
-                if (a.act) { sc = gsc[(size_t)n * Ctot + c0 + c]; sh = gsh[(size_t)n * Ctot + c0 + c]; }
+                if (actv) { sc = gsc[(size_t)n * Ctot + c0 + c]; sh = gsh[(size_t)n * Ctot + c0 + c]; }
 #pragma unroll
                 for (int j = 0; j < NSP; ++j) {
                     float v = raw[c][j];
-                    if (a.act) {
+                    if (actv) {
                         v = v * sc + sh;
                         // SiLU.  (A packed two-element form of this transform measured 1 % slower per forward; separate code
                         // paths per prologue with the exponent's argument as its own multiply-add -- 6 instead of 8 VALU
                         // per value -- gained 1-4 % on most layers but cost the 18-chunk parity-planar reader 65 %.)
-                        if (a.act == 2) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+                        if (actv == 2) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
                     }
                     if (sp_dst[j] >= 0) in_lds[c * DIN_CH + sp_dst[j]] = sp_ok[j] ? v : 0.0f;
                 }
@@ -222,6 +262,7 @@ __global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <=
             const float *ip = in_lds + c * DIN_CH + ty * STRIDE * DIN_P + tx * 4 * STRIDE;
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
+                if (SK && ky != 1) continue;
                 const f32x4 lo = *reinterpret_cast<const f32x4 *>(ip + ky * DIN_P);
                 f32x2 hi = {0.0f, 0.0f};
                 if (KS > 1 && STRIDE == 1) hi = *reinterpret_cast<const f32x2 *>(ip + ky * DIN_P + 4);
@@ -232,8 +273,9 @@ __global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <=
                 const float iv[9] = {lo[0], lo[1], lo[2], lo[3], STRIDE == 1 ? hi[0] : mid[0], STRIDE == 1 ? hi[1] : mid[1], mid[2], mid[3], last};
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
-                    // packed [Cin_pad8][taps][cout_pad] (plain layout), cout_pad >= CO
-                    cfloat *wp = wk + ((size_t)(c0 + c) * TAPS + ky * KS + kx) * a.cout_pad;
+                    if (SK && kx != 1) continue;
+                    // packed [Cin_pad8][taps][cout_pad] (plain layout), cout_pad >= CO; the shortcut's: [Cin_pad8][1][cout_pad]
+                    cfloat *wp = wkv + (SK ? (size_t)(c0 + c) : (size_t)(c0 + c) * TAPS + ky * KS + kx) * cpadv;
                     f32x2 wv[CO / 2];
 #pragma unroll
                     for (int q = 0; q < CO / 2; ++q) wv[q] = f32x2{wp[2 * q], wp[2 * q + 1]};
@@ -245,6 +287,10 @@ __global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <=
             }
         }
     }
+
+    };
+    run_chunks(std::false_type{});
+    if (SKIP) run_chunks(std::true_type{});
 
     static_assert(2 * CO * 256 <= DKC * DIN_CH, "conv_direct: statistics staging does not fit the input tile area");
     direct_epilogue<CO>(a, acc, n, ox0, oy0, tx, ty, in_lds);
@@ -269,8 +315,9 @@ __global__ void __launch_bounds__(256, (CO <= 8 ? 5 : 3)) conv_direct_up2_kernel
     const int tx = lane & 15;
     const int ty = (wave >> 1) * 8 + (lane >> 4) * 2 + (wave & 1);      // row parity = wave & 1
     const int par_a = __builtin_amdgcn_readfirstlane(wave & 1);      // (uniform, and the compiler must know: scalar weight loads)
-    const int n = blockIdx.z;
-    const int ox0 = blockIdx.x * DT_W, oy0 = blockIdx.y * DT_H;
+    const DTile dt = direct_tile();
+    const int n = dt.n;
+    const int ox0 = dt.bx * DT_W, oy0 = dt.by * DT_H;
     const int sx0 = (ox0 >> 1) - 1, sy0 = (oy0 >> 1) - 1;              // source coordinates of LDS (0, 0)
     const int Cin = a.C1, src_plane = a.Hs * a.Ws, plane_bytes = src_plane * 4;
     const int cin_pad = (Cin + 7) / 8 * 8;                              // rows of one parity's weight slab
@@ -356,6 +403,15 @@ int launch_direct(const ConvArgs &a, hipStream_t st)
     dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
     const bool prof = prof_enabled();
     if (prof) prof_before(4, st);
+    if constexpr (KS == 3 && CO >= 8) {
+        if (a.sk_w) {
+            if (a.sk_planar) hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), false, 1, 2>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), false, 1, 1>), grid, dim3(256), 0, st, a);
+            if (prof) prof_after(4, direct_bytes(a), st);
+            IPDM_LAUNCH_CHECK();
+            return IPDM_OK;
+        }
+    }
     if (a.x1_planar) hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), false>), grid, dim3(256), 0, st, a);
     if (prof) prof_after(4, direct_bytes(a), st);
@@ -389,6 +445,15 @@ bool conv_direct_up2_eligible(const ConvArgs &a)
 
 int conv_direct_stats_rows(const ConvArgs &a) { return cdiv(a.Wo, DT_W) * cdiv(a.Ho, DT_H); }
 
+// Can this 3x3 layer (shape fields + the sk_C1 / sk_C2 / sk_cout_pad of the shortcut's input) carry the block's 1x1 shortcut
+// as extra K chunks?  Narrow levels only: 8 or 16 couts on the direct kernel, NCHW input, no residual of its own.
+bool conv_direct_skip_ok(const ConvArgs &a)
+{
+    if (opt(OPT_CONV_NO_DIRECT) || opt(OPT_DIRECT_NO_SKIP_FUSE) || opt(OPT_CONV_NM) > 0) return false;
+    return conv_direct_eligible(a) && a.ksize == 3 && a.stride == 1 && !a.upsample && !a.x1_planar && !a.C2 && !a.res && a.Cout > 4 && a.Cout <= 16 &&
+           a.sk_C1 > 0 && a.sk_C1 + a.sk_C2 <= opt(OPT_DIRECT_MAX_CIN) && a.sk_cout_pad >= 16 && !conv_direct_up2_eligible(a);
+}
+
 int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
 {
     IPDM_REQUIRE(!a.stats || a.stats_rows == conv_direct_stats_rows(a), "conv2d: statistics rows %d != %d", a.stats_rows,
@@ -396,7 +461,8 @@ int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
     IPDM_REQUIRE(!a.x1_planar || (!a.upsample && !(a.Hs & 1) && !(a.Ws & 1)), "conv2d: parity-planar input of odd size %dx%d", a.Hs, a.Ws);
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29),
                  "conv2d: per-sample tensor exceeds the 2 GiB buffer-addressing range");
-    if (conv_nm_eligible(a)) return conv2d_nm_launch(a, st);      // same tiles, same statistics rows: interchangeable
+    IPDM_REQUIRE(!a.sk_w || conv_direct_skip_ok(a), "conv2d: this layer cannot carry a fused shortcut");
+    if (!a.sk_w && conv_nm_eligible(a)) return conv2d_nm_launch(a, st);      // same tiles, same statistics rows: interchangeable
     if (a.stride == 2) {
         if (a.Cout <= 4) return launch_direct_s2<4>(a, st);
         if (a.Cout <= 8) return launch_direct_s2<8>(a, st);

@@ -313,7 +313,8 @@ struct ConvP { float *w = nullptr; float *w_t = nullptr; float *b = nullptr; int
                float *w_up2 = nullptr, *w_up2_t = nullptr;
                float *w_wino = nullptr, *w_wino_t = nullptr; };      // Winograd-domain weights (conv_pack_weights_wino), both orientations
 struct NormP { float *g = nullptr, *b = nullptr; int ch = 0, groups = 0; };
-struct ResP { NormP n1, n2; ConvP c1, c2, sc; bool has_sc = false; int bias_off = 0; };   // bias_off into bias_eff
+struct ResP { NormP n1, n2; ConvP c1, c2, sc; bool has_sc = false; int bias_off = 0;      // bias_off into bias_eff
+              float *b2sc = nullptr; };      // conv2's bias + the shortcut's (the fused form of the narrow levels: conv_direct_skip_ok)
 struct AttnP { NormP n; ConvP qkv, proj; };
 
 struct Arena {
@@ -532,6 +533,12 @@ extern "C" int ipdm_unet_create(const ipdm_unet_cfg *cfg, const float *const *we
                 if ((r = make_conv(net, wm, p + ".conv2.2.weight", p + ".conv2.2.bias", l.cout, l.cout, 3, rp.c2))) break;
                 rp.has_sc = l.cin != l.cout;
                 if (rp.has_sc && (r = make_conv(net, wm, p + ".shortcut.weight", p + ".shortcut.bias", l.cout, l.cin, 1, rp.sc))) break;
+                if (rp.has_sc) {
+                    const float *b2 = wm.get(p + ".conv2.2.bias"), *bs = wm.get(p + ".shortcut.bias");
+                    std::vector<float> both(l.cout);
+                    for (int c = 0; c < l.cout; ++c) both[c] = b2[c] + bs[c];
+                    if ((r = upload(net, both.data(), both.size(), &rp.b2sc))) break;
+                }
                 const float *tw = wm.get(p + ".time_emb.1.weight"), *tbb = wm.get(p + ".time_emb.1.bias"),
                             *cb = wm.get(p + ".conv1.2.bias");
                 if (!tw || !tbb || !cb) { set_error("unet_create: missing time_emb/conv1 bias of %s", p.c_str()); r = IPDM_ERR_INVALID; break; }
@@ -652,8 +659,10 @@ struct Fwd {
 
     // conv over (x1 [,x2]) optionally nearest-upsampled to (H,W); returns a new tensor
     // want_stats: the output feeds a GroupNorm -> the kernel also leaves per-tile partial sums of it (when it can)
+    // sk_*: the block input and shortcut weights of a fused 1x1 shortcut (res_block decides; ConvArgs::sk_*)
     Tensor *conv(const Tensor *x1, const Tensor *x2, const ConvP &cp, int stride, int act, const float *bias,
-                 const Tensor *res, int H, int W, float *ext_out = nullptr, bool want_stats = false)
+                 const Tensor *res, int H, int W, float *ext_out = nullptr, bool want_stats = false,
+                 const Tensor *sk_x1 = nullptr, const Tensor *sk_x2 = nullptr, const ConvP *sk = nullptr)
     {
         const int pad = cp.ks / 2;
         const int Ho = (H + 2 * pad - cp.ks) / stride + 1, Wo = (W + 2 * pad - cp.ks) / stride + 1;
@@ -674,7 +683,14 @@ struct Fwd {
         if (lin2) x2 = lin2;
         if (linr) res = linr;
         a.x1_planar = x1->planar ? 1 : 0;
-        struct LinGuard { Fwd &f; Tensor *a, *b, *c; ~LinGuard() { if (a) f.release(a); if (b) f.release(b); if (c) f.release(c); } } lin_guard{*this, lin1, lin2, linr};
+        Tensor *lins = sk ? linear_copy(sk_x2) : nullptr;
+        if (lins) sk_x2 = lins;
+        struct LinGuard { Fwd &f; Tensor *a, *b, *c, *d; ~LinGuard() { if (a) f.release(a); if (b) f.release(b); if (c) f.release(c); if (d) f.release(d); } }
+            lin_guard{*this, lin1, lin2, linr, lins};
+        if (sk) {
+            a.sk_C1 = sk_x1->C; a.sk_C2 = sk_x2 ? sk_x2->C : 0; a.sk_cout_pad = sk->cout_pad; a.sk_planar = sk_x1->planar ? 1 : 0;
+            a.sk_w = sk->w;
+        }
         if (conv_up2_eligible(a) && !ext_out) o->planar = true;                 // wide levels: parity-planar output
         else if (!conv_direct_up2_eligible(a)) a.w_up2 = nullptr;               // (narrow levels: the direct kernel's parity form writes NCHW)
         // layers with too few tiles to fill the chip are split along K into a scratch buffer (conv_ws.hip)
@@ -707,6 +723,7 @@ struct Fwd {
         a.w = net->transposed ? cp.w_t : cp.w; a.cout_pad = cp.cout_pad; a.w_interleave = cp.interleave; a.bias = bias; a.Cout = cp.cout; a.ksize = cp.ks; a.stride = stride;
         a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = net->gn_scale; a.gn_shift = net->gn_shift;
         a.res = res ? ptr(res) : nullptr;
+        if (sk) { a.sk_x1 = ptr(sk_x1); a.sk_x2 = sk_x2 ? ptr(sk_x2) : nullptr; }
         a.out = ext_out ? ext_out : wptr(o);
         a.tiles_x = a.tiles_y = a.co_tiles = 0;
         rc = conv2d_launch(a, net->st);
@@ -722,7 +739,18 @@ struct Fwd {
         Tensor *h1 = conv(x1, x2, rp.c1, 1, 2, net->bias_eff + rp.bias_off, nullptr, H, W, nullptr, true);
         Tensor *sc = nullptr;
         const Tensor *resid;
-        if (rp.has_sc) { sc = conv(x1, x2, rp.sc, 1, 0, rp.sc.b, nullptr, H, W); resid = sc; }
+        // narrow levels: the 1x1 shortcut rides on conv2 as extra K chunks over the block input (conv_direct.hip)
+        bool fuse = false;
+        if (rp.has_sc && rp.b2sc && rp.sc.interleave == 0 && (!x2 || !x2->planar)) {
+            ConvArgs q;
+            q.C1 = rp.c2.cin; q.C2 = 0; q.B = net->B; q.Cout = rp.c2.cout; q.ksize = 3; q.stride = 1; q.Ho = H; q.Wo = W; q.Hs = H; q.Ws = W; q.H = H; q.W = W;
+            q.upsample = 0; q.act = 2; q.res = nullptr; q.w_interleave = rp.c2.interleave; q.cout_pad = rp.c2.cout_pad; q.x1_planar = 0;
+            q.w_up2 = nullptr; q.w_wino = nullptr;
+            q.sk_C1 = x1->C; q.sk_C2 = x2 ? x2->C : 0; q.sk_cout_pad = rp.sc.cout_pad;
+            fuse = conv_direct_skip_ok(q);
+        }
+        if (fuse) resid = nullptr;
+        else if (rp.has_sc) { sc = conv(x1, x2, rp.sc, 1, 0, rp.sc.b, nullptr, H, W); resid = sc; }
         else if (x2) {   // identity shortcut over a concatenated input: materialise the concat
             sc = make(x1->C + x2->C, H, W);
             Tensor *l1 = linear_copy(x1), *l2 = linear_copy(x2);
@@ -737,7 +765,8 @@ struct Fwd {
             resid = sc;
         } else resid = x1;
         gn(h1, nullptr, rp.n2);
-        Tensor *o = conv(h1, nullptr, rp.c2, 1, 2, rp.c2.b, resid, H, W, nullptr, true);
+        Tensor *o = fuse ? conv(h1, nullptr, rp.c2, 1, 2, rp.b2sc, nullptr, H, W, nullptr, true, x1, x2, &rp.sc)
+                         : conv(h1, nullptr, rp.c2, 1, 2, rp.c2.b, resid, H, W, nullptr, true);
         release(h1);
         if (sc) release(sc);
         return o;
@@ -980,7 +1009,7 @@ extern "C" int ipdm_unet_forward_graph(ipdm_unet *net, const float *d_x, int32_t
     // every per-call switch that changes the recorded launches is part of the key
     const int mode = (opt(OPT_GN_UNFUSED) ? 1 : 0) | ((opt(OPT_UNET_TRANSPOSE) + 1) << 1) | (opt(OPT_CONV_NO_UP2) ? 8 : 0) |
                      (opt(OPT_GN_TWO_STAGE) ? 16 : 0) | (opt(OPT_ATTN_NO_ZSEQ) ? 32 : 0) | (opt(OPT_CONV_NO_WINO) ? 64 : 0) |
-                     (opt(OPT_CONV1X1_NO_QUARTER) ? 128 : 0) | ((opt(OPT_CONV_NM) & 3) << 8);
+                     (opt(OPT_CONV1X1_NO_QUARTER) ? 128 : 0) | ((opt(OPT_CONV_NM) & 3) << 8) | (opt(OPT_DIRECT_NO_SKIP_FUSE) ? 1024 : 0);
     const ipdm_unet::GraphKey key{t, B, H, W, d_x, d_eps, d_ws, mode};
     auto it = net->graphs.find(key);
     if (it != net->graphs.end()) {

@@ -45,6 +45,12 @@ struct ConvArgs {
     // conv_wino_eligible(args) the launcher evaluates the convolution there (conv_wino.hip): 16 instead of 36
     // multiply-adds per 2x2 outputs, same NCHW output and statistics rows as the direct kernel.
     const float *w_wino = nullptr;
+    // The 1x1 shortcut of a ResidualBlock whose channel count changes (Model/model.py:116-130), folded into the block's
+    // SECOND 3x3 convolution on the narrow levels (conv_direct.hip, conv_direct_skip_ok): the block input (sk_x1 [, sk_x2],
+    // same spatial size as this layer's input, sk_x1 possibly parity-planar) and the shortcut's packed weights
+    // [Cin][1][sk_cout_pad]; `bias` then carries both biases and `res` stays null.
+    const float *sk_x1 = nullptr, *sk_x2 = nullptr, *sk_w = nullptr;
+    int sk_C1 = 0, sk_C2 = 0, sk_cout_pad = 0, sk_planar = 0;
     int x1_planar = 0;                  // x1 is stored parity-planar (the output of an up2 convolution)
     int up2 = 0;                        // set by the launcher
     int dbg = 0;                        // IPDM_CONV_DBG bit mask (kernel experiments only; 0 on the product path)
@@ -117,6 +123,7 @@ int conv2d_wino_launch(const ConvArgs &a, hipStream_t st);
 // [Cin/8][Cout/64][xi 16][cout half][k parity][cout 32][k step] = the LDS image of one (chunk, cout tile)
 void conv_pack_weights_wino(const float *w, int Cout, int Cin, std::vector<float> &packed);
 bool conv_ws_planar_ok(const ConvArgs &a);
+bool conv_direct_skip_ok(const ConvArgs &a);       // this 3x3 layer can carry the block's 1x1 shortcut as extra K chunks
 bool conv_direct_up2_eligible(const ConvArgs &a);  // narrow Upsample layers: the same parity form inside conv_direct (NCHW output)
 bool conv_planar_ok(const ConvArgs &a);            // the kernel this convolution runs on can read x1 parity-planar
 // [4 parities][Cin_pad][2x2][cout_pad], each parity packed like a ks = 2 convolution of the same interleave
