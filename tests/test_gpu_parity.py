@@ -843,6 +843,31 @@ def test_unet_full_size_vs_oracle(which):
     assert err <= 5e-5 * max(1.0, want.abs().max().item()), err
 
 
+def test_fused_shortcut_of_the_narrow_levels_equals_its_own_launch():
+    """On the 4/8/16-channel levels the 1x1 shortcut of a ResidualBlock whose channel count changes rides on the block's
+    second 3x3 convolution as extra K chunks (conv_direct.hip, ConvArgs::sk_*); option direct_no_skip_fuse launches it on
+    its own as the reference does (Model/model.py:116-130).  Same function, one rounding less: the production proj UNet
+    (NCHW and parity-planar block inputs, both orientations) agrees to 1e-5 relative, and each form with the oracle."""
+    from ipdm_pytorch_amd import _lib
+    kw = dict(in_channels=1, model_channels=64, out_channels=1, attention_resolutions=(16, 32),
+              channel_mult=(1 / 16, 1 / 8, 1 / 4, 2, 2, 4, 4))
+    net, sd = _native_unet(kw, 5)
+    cfg = ou.UNetConfig(**kw)
+    for shape in ((2, 1, 256, 128), (1, 1, 250, 114)):
+        x = torch.from_numpy(synth.hash_normal(shape, 410))
+        want = ou.unet_forward(cfg, sd, x, 3)
+        outs = []
+        for tr in (0, 1):
+            for off in (0, 1):
+                with _lib.option("unet_transpose", tr), _lib.option("direct_no_skip_fuse", off):
+                    outs.append(net(x.to(DEV), 3).cpu())
+        sc = max(1.0, want.abs().max().item())
+        for o in outs:
+            assert (o - want).abs().max().item() <= 5e-5 * sc
+        assert (outs[0] - outs[1]).abs().max().item() <= 1e-5 * sc and (outs[2] - outs[3]).abs().max().item() <= 1e-5 * sc
+        assert not torch.equal(outs[0], outs[1])       # (the two forms really are different launches)
+
+
 # =========================================================================== sampler loops
 def test_guided_reverse_process_golden(golden):
     from ipdm_pytorch_amd.diffusion import GaussianDiffusion, InjectedNoise
