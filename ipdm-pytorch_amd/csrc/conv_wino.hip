@@ -13,23 +13,30 @@
 // tile schedule, waves 4-7 stage the next K chunk while waves 0-3 multiply), with what Winograd changes:
 //
 //   * workgroup tile = 32 tiles (2 tile rows x 16 tile columns = 4 x 32 output pixels) x 64 couts.  Consumer wave w owns
-//     EIGHT positions -- rows i in {2 ih, 2 ih + 1}, ih = w & 1, all four j -- of one cout half h = w >> 1 for all 32
-//     tiles: 8 accumulators of 32x32 (128 registers).  One 16-byte LDS read per operand and position feeds the four
-//     K steps of a chunk (layouts below): 0.5 LDS instructions per MFMA.
-//   * the producers' VALU job grows from GroupNorm+SiLU to GroupNorm+SiLU + B^T d B: a producer thread owns one
-//     (tile, channel) of the chunk, loads its 4x4 patch itself (16 dword buffer loads with offsets fixed per tile; the
-//     overlap between neighbouring patches is served by L1/L2), activates it, transforms it (32 add/sub) and writes the
-//     16 positions' values into the stage.  The f32 MFMA occupies the SIMD's vector ALU, so this burst runs in the window
-//     between barrier A and the hand-over in which the consumers wait (conv_ws.hip, issue model) -- it is additive.
-//   * the output transform needs all 16 positions of a (tile, cout): in-lane over the wave's own 8 (j, then its two rows),
-//     and ONE exchange of 2 values per (tile, cout) with the partner wave (w ^ 1) through LDS behind a third barrier per
-//     TILE: wave ih = 0 finishes output row 0 of every 2x2 tile, wave ih = 1 row 1.  So a wave stores whole pixel rows
-//     (8-byte stores, 128-byte segments) and the fused GroupNorm statistics keep conv_ws.hip's geometry: one row of
+//     EIGHT positions -- two rows of the 4x4 domain (ih = w & 1: rows 0, 1 or 3, 2 -- row_slot), all four j -- of one cout
+//     half h = w >> 1 for all 32 tiles: 8 accumulators of 32x32 (128 registers).  One 16-byte LDS read per operand and
+//     position feeds the four K steps of a chunk (layouts below): 0.5 LDS instructions per MFMA.  The first chunk of a tile
+//     starts the accumulators (C = 0), so they are dead from the output transform to the next tile.
+//   * producers (waves 4-7; wave pw: tile row pw & 1, four channels of the 8-channel chunk): per chunk and lane three
+//     16-byte buffer loads of the wave's window rows (34 columns, 9 lanes per row; parity-planar x1: 10 lanes, two planes),
+//     two chunks ahead; GroupNorm(+SiLU) ONCE per window element, beside the consumers' MFMAs, into an LDS scratch that
+//     is double-buffered by chunk parity; the weights' LDS image by eight 16-byte loads/stores.  Every step issues the
+//     same 13 loads (one explicit s_waitcnt vmcnt(13)).
+//   * consumers read their 4x4 patches back from the scratch beside the MFMAs and do B^T d B themselves between two
+//     chunks (32 VALU, 16 ds_write_b32 into the stage); ONE hand-over barrier per chunk.
+//   * the output transform needs all 16 positions of a (tile, cout): in-lane over the wave's own 8 (j, then its two rows;
+//     packed-f32), and ONE exchange of 2 values per (tile, cout) with the partner wave (w ^ 1) through LDS behind one barrier
+//     per TILE: wave ih = 0 finishes output row 0 of every 2x2 tile, wave ih = 1 row 1.  The lanes of a tile-column pair sit
+//     16 apart, so v_permlane16_swap gives every lane 4 consecutive pixels of one cout: 16-byte stores and residual loads.
+//     The epilogue is built around LATENCY, not instruction count: the tile's origin comes from the producers through LDS
+//     (no integer divisions in the MFMA waves), all 8 residual loads of a wave are in flight before the transform starts,
+//     the 8 exchange reads are issued together.  Fused GroupNorm statistics with conv_ws.hip's geometry: one row of
 //     per-cout partial sums per pixel row and 32-pixel column block.
 //   * bias: one extra MFMA into position (1, 1), whose output-transform coefficients are 1 for all four outputs.
 //
 // LDS stage (48 KB, two stages): V [xi 16][lk 2][tile 32][kp 4] and U [xi 16][h 2][lk 2][cout 32][kp 4], channel of a
-// value = 2 kp + lk: the four K steps of a lane are one ds_read_b128.  Plus 32 KB exchange, 4 KB statistics staging.
+// value = 2 kp + lk: the four K steps of a lane are one ds_read_b128.  Plus 32 KB exchange, 2 KB statistics staging, 28 KB
+// producer scratch, 32 bytes of tile descriptors.
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -146,8 +153,6 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         const int tid = threadIdx.x - 256, lane = tid & 63;
         const int pw = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int tyw = pw & 1, cg = pw >> 1;
-        const int t16 = lane & 15, kpl = (lane >> 4) & 1, lk = lane >> 5;
-        const int t = 16 * tyw + t16, kp = 2 * cg + kpl;               // channel of the chunk = 2 kp + lk = 4 cg + 2 kpl + lk
         const int q = lane & 3;                                          // G / W1: the lane's channel inside the group
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)a.w, 0, nchunks * a.co_tiles * U_CHUNK_FLOATS * 4, 0x00020000);
@@ -367,7 +372,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         auto step = [&](int s, auto par, f32x4 (&wc)[8], f32x4 (&wn)[8], Raw &rc, Raw &rn) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par)::value;                // s & 1: the stage addresses are compile-time constants
             if (pstamp) p_t = __builtin_amdgcn_s_memtime();
-            const bool more1 = s + 1 < S, more2 = s + 2 < S;
+            const bool more1 = s + 1 < S;
             const int ch1 = ch + 1 == nchunks ? 0 : ch + 1, ch2 = ch1 + 1 == nchunks ? 0 : ch1 + 1;
             issue_w(ch1, wn);
             issue_raw(ch2, rn);
