@@ -417,7 +417,9 @@ def main():
                     "psnr_vs_default_db": round(10 * math.log10(rng * rng / mse), 2) if mse > 0 else None,
                     "max_abs_vs_default": round(float(d.abs().max()), 8), "output_range": round(rng, 6),
                     "note": "exact f32 with the Upsample layers in the reference's 3x3 form (nothing pre-added): the headline minus "
-                            "its one algebraic shortcut; same inputs and noise draws as the headline's last timed step"}
+                            "its one algebraic shortcut; same inputs and noise draws as the headline's last timed step (1-2e-5 is "
+                            "float32 rounding amplified by the sample; a few 1e-4 along a streak in ONE slice is a 4x4 block of the "
+                            "guidance map crossing the jump of the reference's weight_lambda at 1.7: DESIGN 4)"}
                 del den3
             finally:
                 _lib.set_option("conv_no_up2", 0)

@@ -1285,7 +1285,10 @@ def _check_full_size(got, want, phantom, max_rel):
     p_cpu = od.psnr(truth, od.miu2pixel(torch.from_numpy(want[0, 0])).numpy())
     assert abs(p_hip - p_cpu) <= 1e-4 * abs(p_cpu), (p_hip, p_cpu)
     rms = float(np.sqrt((err ** 2).mean()))
-    assert err.max() <= max_rel * scale, (float(err.max()), rms)
+    # (if this ever fires with a few 1e-4 along a streak while the PSNRs above agree: one 4x4 block of the guidance map has
+    #  crossed the JUMP of the reference's weight_lambda at 1.7 -- Utils/train_test_utils.py:831-865, DESIGN 4 -- in one of
+    #  the two float32 evaluations; both are valid, another seed settles it)
+    assert err.max() <= max_rel * scale, (float(err.max()), rms, int((err > max_rel * scale).sum()), "pixels above the bound")
     return float(err.max()), rms, p_hip, p_cpu
 
 
