@@ -206,6 +206,12 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         int vo[3] = {lconst[0], lconst[1], lconst[2]};                   // per-lane load offsets of the tile being loaded
         int g_so = 0;                                                    // ... and the scalar part of its window origin
         int vop[PLANAR ? 3 : 1] = {}, g_sop = 0;                        // the same for chunks of a parity-planar x1
+        // The offsets the window loads actually use: long-lived registers, switched where a tile's chunks change source
+        // (describe(): planar x1; issue_raw(): the first chunk of the NCHW skip half).  Selected per step they were
+        // v_cndmask results placed in the loads' own destination registers, and the waitcnt pass -- which has to assume the
+        // prologue's loads into them still in flight at the loop head -- made every step wait for the PREVIOUS step's loads
+        // before issuing its own: the two-chunk prefetch was gone, the planar kernel producer-bound and 26 % behind.
+        int va[3] = {lconst[0], lconst[1], lconst[2]}, g_sa = 0;
         unsigned g_vmp = 0xfffu, a_vmp = 0xfffu;
         unsigned g_vm = 0xfffu, g_lsh = 0;                              // validity of the 12 loaded elements; left-edge shift
         unsigned a_vm = 0xfffu, a_lsh = 0;
@@ -267,6 +273,9 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
                     //  returns as 0: tools/ubench/oob_probe.hip; either way those elements are masked by g_vm)
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) va[j] = PLANAR ? vop[PLANAR ? j : 0] : vo[j];      // chunk 0 of a tile is x1's
+            g_sa = PLANAR ? g_sop : g_so;
         };
         struct Raw { f32x4 v[3]; float sc, sh; bool planar; };
         Raw rawA, rawB;
@@ -296,15 +305,14 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
             // tiles: range-checked per-lane offsets; describe() put whichever applies into vo[]
             const int cb = ((from1 ? c0 : c0 - a.C1) + 4 * cg) * plane_bytes;
             r.planar = PLANAR && from1;
-            if (PLANAR && from1) {       // (uniform) only x1 is stored parity-planar; the skip half of a concat is NCHW
+            if (PLANAR && c0 == a.C1) {  // (uniform, once per tile) only x1 is stored parity-planar; the skip half of a concat is NCHW
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    r.v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vop[PLANAR ? j : 0], cb + g_sop, 0));
-            } else {
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    r.v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo[j], cb + g_so, 0));
+                for (int j = 0; j < 3; ++j) va[j] = vo[j];
+                g_sa = g_so;
             }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                r.v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, va[j], cb + g_sa, 0));
             const int gso = (g_n * Ctot + c0 + 4 * cg) * 4;
             r.sc = bload(gsc_rsrc, q * 4, gso);
             r.sh = bload(gsh_rsrc, q * 4, gso);
