@@ -41,9 +41,10 @@ constexpr int DT_W = 64, DT_H = 16;
 // Which tile a workgroup takes.  Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), so with
 // tile = blockIdx the horizontal and vertical neighbours of every tile run on OTHER XCDs and each XCD's L2 fetches the
 // halo columns and rows again: a 64-pixel row segment with its two halo pixels touches four 128-byte lines, two of them
-// for one pixel each (rocprofv3 FETCH_SIZE of the 8 -> 8 layer: 1.5x its algorithmic reads, and the kernel sits at 5.3 TB/s
-// of REAL traffic -- profiles/r03b_hbm_by_kernel.csv).  Here XCD x takes the x-th contiguous eighth of the tile sequence in
-// row-major order, so neighbouring tiles share an L2 and run close in time.  A bijection for any grid size.
+// for one pixel each (rocprofv3 FETCH_SIZE of the 8 -> 8 layer: 1.55x its algorithmic reads).  Here XCD x takes the x-th
+// contiguous eighth of the tile sequence in row-major order, so neighbouring tiles share an L2 and run close in time: fetch
+// traffic -40 % (profiles/r03g_hbm_by_kernel.csv), kernel time -1.6 % -- the re-fetches had come from the memory-side cache
+// and the kernel is issue-bound.  A bijection for any grid size.
 struct DTile { int bx, by, n; };
 __device__ inline DTile direct_tile()
 {
@@ -154,7 +155,7 @@ __device__ inline void direct_epilogue(const ConvArgs &a, f32x2 (&acc)[4][CO / 2
 // SKIP (1: NCHW, 2: its x1 parity-planar): the ResidualBlock's 1x1 shortcut over the block input (Model/model.py:116-130,
 // ConvArgs::sk_*) as EXTRA K chunks of this (the block's second) 3x3 convolution -- centre tap only, no prologue, into the same
 // accumulators.  The shortcut's launch, the write of its output and the read of that output as this layer's residual
-// disappear: 2 * Cout * 4 bytes per pixel of a family that runs at 5.3 TB/s of real HBM traffic.
+// disappear, and with them one staging pass over the block input's tile.
 template <int CO, int KS, int DKC, bool PLANAR, int STRIDE = 1, int SKIP = 0>
 __global__ void __launch_bounds__(256, (STRIDE == 2 ? (CO <= 8 ? 4 : 3) : (CO <= 4 ? 6 : (CO <= 8 ? 5 : 3)))) conv_direct_kernel(ConvArgs a)
 {
