@@ -394,7 +394,7 @@ int conv_stats_rows(const ConvArgs &a)
 
 int conv_split(const ConvArgs &a)
 {
-    if (conv_sx_pieces(a.w_interleave) || !a.w_interleave) return 1;
+    if (conv_sx_pieces(a.w_interleave) || !a.w_interleave || conv_wino_eligible(a)) return 1;
     return conv_ws_split(a);
 }
 size_t conv_split_ws_bytes(const ConvArgs &a)

@@ -723,7 +723,15 @@ bool conv_wino_eligible(const ConvArgs &a)
     const int Ctot = a.C1 + a.C2;
     if (a.Cout % BN || Ctot % KC || Ctot < 32 || (a.C2 && a.C1 % KC)) return false;
     if ((a.x1_planar && ((a.Hs | a.Ws) & 1)) || conv_up2_eligible(a)) return false;
-    return conv_ws_split(a) == 1;
+    if (conv_ws_split(a) == 1) return true;
+    // Layers the direct tiling splits along K (<= 16 tiles of 8x32x128 per sample): this tiling has 4-8x more tiles (4x32
+    // pixels x 64 couts), enough to fill the chip at the benched batch without a split.  OPT-IN (wino_split_min_tiles = N > 0:
+    // taken from N tiles per sample; a rule of the layer alone): measured with N = 64 on 256->256 @63x29, 1.59x faster at B = 8
+    // (0.125 vs 0.199 ms: +1.2 % on the benched step) and 1.4-1.6x SLOWER for a lone slice (64 workgroups with one
+    // 32-chunk tile each: 0.057 vs 0.041 ms, +1.8 % on the B = 1 latency) -- the default keeps the lone slice.
+    const int min_tiles = opt(OPT_WINO_SPLIT_MIN_TILES);
+    const long wt = (long)cdiv(a.Ho, TH) * cdiv(a.Wo, TW) * (a.Cout / BN);
+    return min_tiles > 0 && wt >= min_tiles;
 }
 
 bool conv_wino_shape_ok(int Cout, int Cin, int ks, int stride, int interleave)

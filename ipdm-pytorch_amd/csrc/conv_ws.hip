@@ -744,7 +744,7 @@ bool conv_up2_eligible(const ConvArgs &a)
 int conv_ws_stats_rows(const ConvArgs &a)
 {
     if (conv_up2_eligible(a)) return 4 * a.Hs * cdiv(a.Ws, 32);
-    if (a.split_ws && conv_ws_split(a) > 1) return cdiv((long)a.Ho * a.Wo, SPLIT_PIX);
+    if (a.split_ws && conv_ws_split(a) > 1 && !conv_wino_eligible(a)) return cdiv((long)a.Ho * a.Wo, SPLIT_PIX);
     return a.Ho * cdiv(a.Wo, 32);      // one row per pixel row and 32-pixel tile column: independent of the tile variant
 }
 

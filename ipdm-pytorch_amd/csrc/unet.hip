@@ -1009,7 +1009,8 @@ extern "C" int ipdm_unet_forward_graph(ipdm_unet *net, const float *d_x, int32_t
     // every per-call switch that changes the recorded launches is part of the key
     const int mode = (opt(OPT_GN_UNFUSED) ? 1 : 0) | ((opt(OPT_UNET_TRANSPOSE) + 1) << 1) | (opt(OPT_CONV_NO_UP2) ? 8 : 0) |
                      (opt(OPT_GN_TWO_STAGE) ? 16 : 0) | (opt(OPT_ATTN_NO_ZSEQ) ? 32 : 0) | (opt(OPT_CONV_NO_WINO) ? 64 : 0) |
-                     (opt(OPT_CONV1X1_NO_QUARTER) ? 128 : 0) | ((opt(OPT_CONV_NM) & 3) << 8) | (opt(OPT_DIRECT_NO_SKIP_FUSE) ? 1024 : 0);
+                     (opt(OPT_CONV1X1_NO_QUARTER) ? 128 : 0) | ((opt(OPT_CONV_NM) & 3) << 8) | (opt(OPT_DIRECT_NO_SKIP_FUSE) ? 1024 : 0) |
+                     (opt(OPT_WINO_SPLIT_MIN_TILES) << 11);
     const ipdm_unet::GraphKey key{t, B, H, W, d_x, d_eps, d_ws, mode};
     auto it = net->graphs.find(key);
     if (it != net->graphs.end()) {

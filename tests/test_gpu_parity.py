@@ -556,6 +556,17 @@ def test_fused_groupnorm_statistics_chain(case):
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
 
 
+def test_k_split_layers_on_the_winograd_kernel_opt_in():
+    """Option wino_split_min_tiles (off by default: DESIGN 8): layers the direct tiling splits along K take the Winograd
+    kernel instead -- same tolerance, same fused statistics rows as every other producer."""
+    from ipdm_pytorch_amd import _lib
+    with _lib.option("wino_split_min_tiles", 16):
+        for i, case in enumerate([(1, 256, 0, 32, 32, 32, 32, 256, 3, 1, 2, True), (1, 256, 256, 16, 24, 16, 24, 256, 3, 1, 2, False),
+                                  (2, 256, 0, 63, 29, 63, 29, 256, 3, 1, 2, True)]):
+            _conv_case(*case, seed=7100 + i)
+        test_fused_groupnorm_statistics_chain((1, 256, 32, 32, 256, 3, 1, True, 2, 64))
+
+
 def test_narrow_convolutions_on_the_16_cout_mfma_opt_in():
     """conv_nm.hip (option conv_nm, off by default: DESIGN 6, negative results): the narrow stride-1 layers on
     v_mfma_f32_16x16x4_f32 -- single convolutions (3x3 / 1x1, 8 and 16 couts, concat, every channel-group count, ragged
