@@ -43,7 +43,7 @@ constexpr int DT_W = 64, DT_H = 16;
 // halo columns and rows again: a 64-pixel row segment with its two halo pixels touches four 128-byte lines, two of them
 // for one pixel each (rocprofv3 FETCH_SIZE of the 8 -> 8 layer: 1.55x its algorithmic reads).  Here XCD x takes the x-th
 // contiguous eighth of the tile sequence in row-major order, so neighbouring tiles share an L2 and run close in time: fetch
-// traffic -40 % (profiles/r03g_hbm_by_kernel.csv), kernel time -1.6 % -- the re-fetches had come from the memory-side cache
+// traffic -40 % (profiles/r03k_hbm_by_kernel.csv), kernel time -1.6 % -- the re-fetches had come from the memory-side cache
 // and the kernel is issue-bound.  A bijection for any grid size.
 struct DTile { int bx, by, n; };
 __device__ inline DTile direct_tile()
