@@ -272,6 +272,15 @@ int ipdm_bench_attention(int32_t B, int32_t heads, int32_t d, int32_t T, int32_t
  * weights are packed): 0 = plain layout (direct / legacy kernels), 2 | 4 = conv_ws cout-interleaved f32 MFMA,
  * 102 | 103 = opt-in split-bf16 (IPDM_CONV_SPLIT=2|3).  Test aid: lets a parity test prove which path it ran. */
 int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
+/* Which KERNEL a plain convolution (one source, no resampling on the way in, K-split workspace available) of this shape
+ * and batch takes NOW -- the dispatch of the executor's conv2d_launch, options included:
+ *   1 = conv_wino (Winograd F(2x2,3x3), 64-cout tiles)      2 = conv_wino2 (Winograd, 128-cout tiles: the dominant kernel)
+ *   3 = conv_ws (direct implicit GEMM, f32 MFMA)            4 = conv_ws with a K split + combine pass
+ *   5 = conv_direct (narrow layers, packed-f32 VALU)        6 = conv_nm (opt-in 16-cout MFMA)
+ *   7 = parity form of an Upsample (never for this plain shape)   8 = conv_igemm (the generic 4-wave kernel)
+ *   102 | 103 = opt-in split-bf16;  -1 = bad argument.
+ * Test aid (replaces nothing in the reference): a parity test asserts the kernel it believes it covers. */
+int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W);
 /* Which attention kernel a launch with head dim d takes NOW: 0 = 4-wave kernel (d = 32, or IPDM_ATTN_LEGACY),
  * 1 = wave-specialised exact-f32 MFMA (the default for d = 64), 3 = opt-in split-bf16 (IPDM_ATTN_SPLIT=3). */
 int32_t ipdm_attention_kernel_code(int32_t d);

@@ -30,7 +30,7 @@ const OptDef g_opt_def[OPT_COUNT] = {
     {"conv_legacy", 0, false}, {"conv1x1_legacy", 0, false}, {"convs2_legacy", 0, false},
     {"conv_no_direct", 0, false}, {"direct_no_planar", 0, false}, {"direct_max_cin", 160, false}, {"direct_no_s2", 0, false}, {"direct_no_skip_fuse", 0, true},
     {"conv_sx_cw2", 0, false}, {"conv_dbg", 0, true}, {"conv_vec4_strict", 0, false}, {"conv_no_splitk", 0, false},
-    {"conv_no_wino", 0, true}, {"wino_split_min_tiles", 0, true}, {"conv1x1_no_quarter", 0, true}, {"conv_nm", 0, true},
+    {"conv_no_wino", 0, true}, {"wino_v1", 0, true}, {"wino2_min_tiles", 192, true}, {"wino_split_min_tiles", 0, true}, {"conv1x1_no_quarter", 0, true}, {"conv_nm", 0, true},
     {"gn_two_stage", 0, true}, {"gn_unfused", 0, true},
     {"unet_transpose", -1, true},
     {"attn_no_kvsplit", 0, false}, {"attn_legacy", 0, false}, {"attn_no_zseq", 0, true},

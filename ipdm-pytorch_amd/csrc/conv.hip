@@ -383,6 +383,19 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
     return IPDM_ERR_UNSUPPORTED;
 }
 
+// mirrors the dispatch of conv2d_launch: WHICH kernel this convolution runs on now (ipdm_conv_kernel_code)
+int conv_kernel_code(const ConvArgs &a)
+{
+    if (conv_sx_pieces(a.w_interleave)) return 100 + conv_sx_pieces(a.w_interleave);
+    if (a.w_interleave) {
+        if (conv_up2_eligible(a)) return 7;
+        if (conv_wino_eligible(a)) return (!opt(OPT_WINO_V1) && conv_wino2_eligible(a)) ? 2 : 1;
+        return (a.split_ws && conv_ws_split(a) > 1) ? 4 : 3;
+    }
+    if (!opt(OPT_CONV_NO_DIRECT) && conv_direct_eligible(a)) return conv_nm_eligible(a) ? 6 : 5;
+    return 8;
+}
+
 // mirrors the dispatch of conv2d_launch: rows of fused output statistics of the kernel this convolution runs on
 int conv_stats_rows(const ConvArgs &a)
 {

@@ -769,7 +769,7 @@ int conv2d_wino_launch(const ConvArgs &args, hipStream_t st)
     a.tiles_y = cdiv(a.Ho, TH);
     a.co_tiles = a.Cout / BN;
     a.ksplit = 1;
-    a.dbg = a.dbg_buf ? (opt(OPT_CONV_DBG) & 56) : 0;
+    a.dbg = (a.dbg_buf ? (opt(OPT_CONV_DBG) & 56) : 0) | (opt(OPT_CONV_DBG) & 7);
     IPDM_REQUIRE(conv_wino_eligible(args), "conv2d_wino: layer not eligible");
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29) &&
                      (long)a.Cout * a.Ho * a.Wo < (1L << 29) && (long)(a.C1 + a.C2) / KC * a.co_tiles * U_CHUNK_FLOATS < (1L << 29),
@@ -784,7 +784,9 @@ int conv2d_wino_launch(const ConvArgs &args, hipStream_t st)
     if (int rc = ensure_dynamic_lds(fn, LDS_BYTES)) return rc;
     const bool prof = prof_enabled();
     if (prof) prof_before(3, st);
-    if (a.x1_planar) hipLaunchKernelGGL(conv_wino_kernel<true>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    if (!opt(OPT_WINO_V1) && conv_wino2_eligible(a)) {
+        if (int rc = conv2d_wino2_launch(a, st)) return rc;
+    } else if (a.x1_planar) hipLaunchKernelGGL(conv_wino_kernel<true>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
     else hipLaunchKernelGGL(conv_wino_kernel<false>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
     // EXECUTED flops: 16 multiply-adds per 2x2 output tile and (cin, cout) pair (the 3x3 form counts 36)
     if (prof) prof_after(3, 2.0 * a.B * (double)cdiv(a.Ho, 2) * cdiv(a.Wo, 2) * 16.0 * a.Cout * (a.C1 + a.C2), st);

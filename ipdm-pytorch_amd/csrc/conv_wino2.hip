@@ -1,0 +1,582 @@
+// Winograd F(2x2, 3x3) form of the wide 3x3 stride-1 convolutions on the exact-f32 MFMA (gfx950) -- round-4 structure.
+//
+//     Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// 16 multiply-adds per 2x2 outputs and (cin, cout) pair instead of 36: the contraction over channels is 16 independent
+// GEMMs [tiles x cin] x [cin x cout], one per position xi = (i, j) of the 4x4 transform domain, on v_mfma_f32_32x32x2_f32.
+// U = G g G^T is formed in double precision when the weights are packed and rounded once (conv_wino.hip).
+//
+// What changed against the round-3 kernel (conv_wino.hip: still the kernel of the 64-cout layers and the A/B arm
+// `wino_v1`).  v_mfma_f32_32x32x2_f32 shares its SIMD's vector ALU: everything that is not an MFMA -- GroupNorm+SiLU of the
+// window, B^T d B, the operand reads, the output transform -- is paid for in matrix-pipe time, in the MFMA wave itself
+// (~9 cycles per instruction) or beside another wave's MFMA stream (a partner's VALU issues at ~1 per 25 cycles there:
+// tools/ubench/coissue.hip, and the stamps of the first round-4 attempt -- two independent 256-thread workgroups per CU,
+// every wave staging AND multiplying -- showed each wave's staging phase longer than its partner's MFMA phase: no gain).
+// The staging work of a chunk is per (pixel, channel); the MFMA work is per (pixel, channel, COUT).  So this kernel doubles
+// the couts a workgroup multiplies per staged window:
+//
+//   * one 512-thread workgroup per CU, tile = 32 Winograd tiles (4 x 32 pixels) x 128 couts; all EIGHT waves multiply:
+//     wave w owns positions 8 (w & 1) .. +7 of cout quarter (w >> 1) for all 32 tiles (8 accumulators of 32x32);
+//   * all eight waves stage: wave w the window rows of tile row (w & 1) for four channels (w >> 1) of each SIXTEEN-channel
+//     chunk (three 16-byte buffer loads per lane, GroupNorm+SiLU once per window element, wave-private LDS scratch), reads
+//     its (tile, channel) patches back and does B^T d B into the shared V stage: per MFMA half the staging instructions of
+//     the round-3 kernel, and none of them in a wave that only stages;
+//   * the U operands never touch LDS: a lane's four k steps of one position are 16 contiguous bytes of the packed image
+//     ([8-channel chunk][64-cout tile][xi][h][lk][cout 32][kp 4], unchanged), loaded from L2 straight into the MFMA's A
+//     registers half a chunk ahead, each position's registers reloaded in place right after its MFMAs: 32 registers;
+//   * one barrier per 16-channel chunk (64 MFMAs per wave); V double-buffered, the scratch private to its wave.
+// The output transform, the partner exchange, the fused statistics and every layout are the round-3 ones.
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+#include "unet_kernels.h"
+
+using namespace ipdm;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef IPDM_CONV_STAMPS
+#define IPDM_CONV_STAMPS 0          // `make stamps`: in-kernel s_memtime stamps of the phases (a stamped build changes what it measures)
+#endif
+
+namespace {
+
+constexpr int KC = 16;                                 // channels per staged chunk: two MFMA sub-chunks of 8 (4 k-steps of 2)
+constexpr int TH = 4, TW = 32, BN = 128;               // output pixels / couts of a workgroup tile
+constexpr int NW = 8;                                  // waves
+constexpr int VH_FLOATS = 16 * 2 * 32 * 4;             // V of 8 channels [xi 16][lk 2][tile 32][kp 4]: 16 KB
+constexpr int V_FLOATS = 2 * VH_FLOATS;                // a stage: both sub-chunks
+constexpr int U_CHUNK_FLOATS = 16 * 2 * 2 * 32 * 4;    // packed weights of one (8-channel chunk, 64-cout tile)
+constexpr int XCH_FLOATS = NW * 8 * 64 * 4;            // per wave: 8 x (64 lanes x 16 bytes)
+constexpr int XP = 40;                                 // scratch row pitch (34 window columns; planar: columns up to 39)
+constexpr int XWAVE = 16 * XP + 64 * 4 + 8;            // per wave: 16 row segments + a dump slot per lane
+constexpr size_t LDS_BYTES = (size_t)(2 * V_FLOATS + XCH_FLOATS + NW * XWAVE) * sizeof(float);
+static_assert(LDS_BYTES <= 160 * 1024, "conv_wino2: LDS budget exceeded");
+static_assert(128 <= XWAVE, "conv_wino2: the statistics staging aliases the wave's scratch");
+
+struct TileId { int n, oy0, ox0, co0; };
+
+__host__ __device__ constexpr int row_slot(int i) { return i ^ (i >> 1); }      // rows of the transform domain in the order 0, 1, 3, 2
+
+__device__ inline TileId decode_tile(const ConvArgs &a, int tile)
+{
+    TileId t;
+    const int co_t = tile % a.co_tiles;
+    int rest = tile / a.co_tiles;
+    const int tx = rest % a.tiles_x;
+    rest /= a.tiles_x;
+    const int ty = rest % a.tiles_y;
+    t.n = rest / a.tiles_y;
+    t.oy0 = ty * TH;
+    t.ox0 = tx * TW;
+    t.co0 = co_t * BN;
+    return t;
+}
+
+constexpr int OOB = 0x7fffffff;                        // per-lane buffer offset out of range: loads return 0, stores are dropped
+
+__device__ inline float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+template <bool PLANAR>
+__global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *const xch = lds + 2 * V_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *const xw = lds + 2 * V_FLOATS + XCH_FLOATS + swave * XWAVE;      // the wave's scratch (statistics staging in the epilogue)
+
+    // static tile schedule: the workgroups of one XCD take a contiguous run of tiles, slot rotated per round
+    const int G = gridDim.x, per = G >> 3;
+    const int local = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int rounds = (ntiles + G - 1) / G;
+    auto tile_of = [&](int k) { return k * G + (local + 5 * k) % G; };
+    const int n_my = rounds == 0 ? 0 : (tile_of(rounds - 1) < ntiles ? rounds : rounds - 1);
+    const int Ctot = a.C1 + a.C2;
+    const int nchunks = Ctot / KC;                       // launcher: Ctot % KC == 0, C1 % KC == 0, nchunks >= 2
+    const int S = n_my * nchunks;
+    const int plane_bytes = a.Hs * a.Ws * 4;
+    if (S == 0) return;
+
+    // =============================================================================== staging role
+    // wave w: tile row w & 1 (4 input rows x 34 columns of the 16 tiles of that row), channels 4 (w >> 1) .. +3 of the 16-channel chunk
+    const int tyw = swave & 1, cg = swave >> 1;
+    const int q = lane & 3;                                              // the lane's channel inside the group
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.w, 0, 2 * nchunks * 2 * a.co_tiles * U_CHUNK_FLOATS * 4, 0x00020000);      // (a.co_tiles counts 128-cout tiles)
+    // slot u = (lane >> 2) + 16 j  ->  (row r, 4-float part) of the lane's channel; 36 of the 48 slots exist
+    int lconst[3], xoff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int u = (lane >> 2) + 16 * j, r = u / 9, part = u - r * 9;
+        const bool v = u < 36;
+        lconst[j] = v ? (r * a.Ws + 4 * part) * 4 + q * plane_bytes : OOB;
+        xoff[j] = v ? (q * 4 + r) * XP + (PLANAR ? 2 : 4) * part : 16 * XP + lane * (PLANAR ? 2 : 4);
+    }
+    // parity-planar x1 ([ch][row & 1][col & 1][H/2][W/2]): 10 lanes per window row (5 x 16 bytes per plane), the scratch row
+    // de-interleaved [even window columns: 20][odd: 20] (conv_wino.hip has the reasoning)
+    int lconstp[PLANAR ? 3 : 1], xoffp[PLANAR ? 3 : 1];
+    const int h2 = a.Hs >> 1, w2 = a.Ws >> 1;
+    if (PLANAR) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int u = (lane >> 2) + 16 * j, r = u / 10, part = u - r * 10;
+            const bool v = u < 40;
+            const int px = part < 5 ? 1 : 0, py = (r + 1) & 1, yo = r == 0 ? -1 : (r == 3 ? 1 : 0);
+            const int xo = px ? 4 * part - 1 : 4 * (part - 5);
+            lconstp[PLANAR ? j : 0] = v ? (((py * 2 + px) * h2 + yo) * w2 + xo) * 4 + q * plane_bytes : OOB;
+            xoffp[PLANAR ? j : 0] = v ? (q * 4 + r) * XP + (px ? 4 * part : 20 + 4 * (part - 5)) : 16 * XP + lane * 4;
+        }
+    }
+    // tile descriptors: issue side (g_*: the tile whose chunks are being LOADED), activation side (a_*: one chunk behind)
+    int g_n = 0, g_co = 0, g_oy = 0, g_ox = 0;
+    const float *g_src1 = a.x1, *g_src2 = a.x2 ? a.x2 : a.x1;
+    bool g_bord = false;
+    int vo[3] = {lconst[0], lconst[1], lconst[2]}, g_so = 0;             // NCHW offsets of the tile being loaded
+    int va[3] = {lconst[0], lconst[1], lconst[2]}, g_sa = 0;             // the offsets the loads use (planar x1 / NCHW)
+    int vop[PLANAR ? 3 : 1] = {}, g_sop = 0;
+    unsigned g_vmp = 0xfffu, a_vmp = 0xfffu, g_vm = 0xfffu, g_lsh = 0, a_vm = 0xfffu, a_lsh = 0;
+    bool a_bord = false;
+    auto describe = [&](int k) __attribute__((always_inline)) {
+        const TileId tl = decode_tile(a, tile_of(k));
+        const int iy0 = tl.oy0 - 1 + 2 * tyw, ix0 = tl.ox0 - 1;
+        g_n = tl.n; g_co = tl.co0 / BN; g_oy = tl.oy0; g_ox = tl.ox0;
+        g_src1 = a.x1 + (size_t)tl.n * a.C1 * (plane_bytes / 4);
+        g_src2 = a.x2 ? a.x2 + (size_t)tl.n * a.C2 * (plane_bytes / 4) : g_src1;
+        g_bord = tl.oy0 - 1 < 0 || tl.ox0 - 1 < 0 || tl.oy0 + TH + 1 > a.H || tl.ox0 + TW + 1 > a.W;
+        const int g_base = (iy0 * a.Ws + ix0) * 4;
+        g_so = g_bord ? 0 : g_base;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vo[j] = lconst[j];
+        if (PLANAR) {
+            const int basep = (((tl.oy0 >> 1) + tyw) * w2 + (tl.ox0 >> 1)) * 4;
+            g_sop = g_bord ? 0 : basep;
+            g_vmp = 0xfffu;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vop[PLANAR ? j : 0] = lconstp[PLANAR ? j : 0];
+            if (g_bord) {
+                g_vmp = 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int u = (lane >> 2) + 16 * j, r = u / 10, part = u - r * 10;
+                    const int c0 = part < 5 ? 8 * part : 8 * (part - 5) + 1;
+                    const bool rowok = u < 40 && iy0 + r >= 0 && iy0 + r < a.H;
+                    vop[PLANAR ? j : 0] = rowok ? lconstp[PLANAR ? j : 0] + basep : OOB;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = c0 + 2 * e, ix = ix0 + c;
+                        g_vmp |= (rowok && ix >= 0 && ix < a.W && c < 34) ? 1u << (4 * j + e) : 0u;
+                    }
+                }
+            }
+        }
+        if (g_bord) {
+            g_vm = 0; g_lsh = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int u = (lane >> 2) + 16 * j, r = u / 9, part = u - r * 9;
+                const bool rowok = u < 36 && iy0 + r >= 0 && iy0 + r < a.H;
+                // the 16 bytes of the leftmost part of an image row start one pixel before the row: shifted by one pixel and
+                // rotated back after the load (at the very first row they would start before the buffer)
+                const bool lsh = rowok && ix0 + 4 * part < 0;
+                g_lsh |= lsh ? 1u << j : 0u;
+                vo[j] = rowok ? lconst[j] + g_base + (lsh ? 4 : 0) : OOB;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ix = ix0 + 4 * part + e;
+                    g_vm |= (rowok && ix >= 0 && ix < a.W && 4 * part + e < 34) ? 1u << (4 * j + e) : 0u;
+                }
+                // (a load of a border tile may straddle the end of an image row: the next row's pixels, or -- at the last row
+                //  of the tensor -- dwords past num_records, which a raw buffer load range-checks one by one and returns as
+                //  0: tools/ubench/oob_probe.hip; either way those elements are masked by g_vm)
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) va[j] = PLANAR ? vop[PLANAR ? j : 0] : vo[j];      // chunk 0 of a tile is x1's
+        g_sa = PLANAR ? g_sop : g_so;
+    };
+    struct Raw { f32x4 v[3]; float sc, sh; bool planar; };
+    Raw raw;
+    const __amdgpu_buffer_rsrc_t gsc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.act ? a.gn_scale : a.out), 0, a.act ? (a.B * Ctot + 64) * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsh_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.act ? a.gn_shift : a.out), 0, a.act ? (a.B * Ctot + 64) * 4 : 0, 0x00020000);
+    // every iteration issues the same loads, needed or not (past the end of the stream they re-read chunks of the last tile:
+    // valid addresses, results unused): with conditional issue the waitcnt pass has to assume the shortest path
+    auto issue_raw = [&](int ch) __attribute__((always_inline)) {
+        const int c0 = ch * KC;
+        const bool from1 = c0 < a.C1;
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(from1 ? g_src1 : g_src2), 0, (from1 ? a.C1 : a.C2) * plane_bytes, 0x00020000);
+        const int cb = ((from1 ? c0 : c0 - a.C1) + 4 * cg) * plane_bytes;
+        raw.planar = PLANAR && from1;
+        if (PLANAR && c0 == a.C1) {  // (uniform, once per tile) only x1 is stored parity-planar; the skip half of a concat is NCHW
+#pragma unroll
+            for (int j = 0; j < 3; ++j) va[j] = vo[j];
+            g_sa = g_so;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            raw.v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, va[j], cb + g_sa, 0));
+        const int gso = (g_n * Ctot + c0 + 4 * cg) * 4;
+        raw.sc = bload(gsc_rsrc, q * 4, gso);
+        raw.sh = bload(gsh_rsrc, q * 4, gso);
+    };
+    // activate the 12 landed values, zero what lies outside the image, park them in the wave's scratch
+    auto activate = [&]() __attribute__((always_inline)) {
+        f32x2 d[6];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { d[2 * j] = f32x2{raw.v[j][0], raw.v[j][1]}; d[2 * j + 1] = f32x2{raw.v[j][2], raw.v[j][3]}; }
+        const bool pl = PLANAR && raw.planar;
+        if (a_bord && !pl) {  // (uniform) undo the left-edge shift: {x0, x1, x2, x3} loaded from one pixel further right
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (a_lsh >> j & 1) { d[2 * j + 1] = f32x2{d[2 * j][1], d[2 * j + 1][0]}; d[2 * j] = f32x2{0.0f, d[2 * j][0]}; }
+        }
+        if (a.act) {
+            const f32x2 sc2 = {raw.sc, raw.sc}, sh2 = {raw.sh, raw.sh};
+#pragma unroll
+            for (int e = 0; e < 6; ++e) d[e] = __builtin_elementwise_fma(d[e], sc2, sh2);
+            if (a.act == 2) {
+                f32x2 ex[6];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) ex[e] = d[e] * -1.4426950408889634f;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) { ex[e][0] = __builtin_amdgcn_exp2f(ex[e][0]); ex[e][1] = __builtin_amdgcn_exp2f(ex[e][1]); }
+#pragma unroll
+                for (int e = 0; e < 6; ++e) ex[e] = ex[e] + 1.0f;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) { ex[e][0] = __builtin_amdgcn_rcpf(ex[e][0]); ex[e][1] = __builtin_amdgcn_rcpf(ex[e][1]); }
+#pragma unroll
+                for (int e = 0; e < 6; ++e) d[e] = d[e] * ex[e];
+            }
+        }
+        if (a_bord) {
+            const unsigned vm = pl ? a_vmp : a_vm;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) d[e >> 1][e & 1] = (vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
+        }
+        if (pl) {            // every other window column: the de-interleaved half of the scratch row
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                *reinterpret_cast<f32x4 *>(xw + xoffp[PLANAR ? j : 0]) = f32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
+        } else if (PLANAR) { // four consecutive columns into the de-interleaved row (one scratch format per instantiation)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float *dst = xw + xoff[j];
+                dst[0] = d[2 * j][0]; dst[1] = d[2 * j + 1][0];
+                dst[20] = d[2 * j][1]; dst[21] = d[2 * j + 1][1];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                *reinterpret_cast<f32x4 *>(xw + xoff[j]) = f32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
+        }
+    };
+
+    // =============================================================================== multiplying role
+    const int lk = lane >> 5, l31 = lane & 31;
+    const int ih = swave & 1, hq = swave >> 1;             // which two rows of the transform domain, which cout quarter
+    // the lane's tile inside the workgroup tile: row ty, column 2 txh + odd.  The two tiles of a column pair sit 16 lanes
+    // apart (DPP rows r, r + 1), so that the epilogue's exchange of halves is one v_permlane16_swap per register pair
+    const int odd = l31 >> 4, ty = l31 & 1, txh = (l31 & 15) >> 1;
+    f32x16 acc[8];
+    f32x4 ua[8];                                           // the A operands (U) of the wave's 8 positions: four k steps each
+    const int out_plane = a.Ho * a.Wo;
+    const int plane4 = out_plane * 4;
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
+    float nb = 0.0f;
+    auto fetch_bias = [&](int co0) __attribute__((always_inline)) {
+        nb = bload(b_rsrc, lk ? OOB : l31 * 4, (co0 + hq * 32) * 4);
+    };
+    const float sgn = ih == 0 ? 1.0f : -1.0f;
+    // input transform: the wave transforms the (tile, channel) pairs of its own scratch -- lane map 16 tiles x 2 k-steps x 2
+    // channel parities, so that the 32 lanes of an LDS store group write a 64-float span of the [tile][k-step] image at most
+    // 2-way conflicted (free)
+    const int w_t16 = lane & 15, w_kpl = (lane >> 4) & 1;
+    const float *const xr = xw + ((2 * w_kpl + lk) * 4) * XP + 2 * w_t16;
+    const int v_slot = (w_t16 & 1) * 16 + (w_t16 >> 1) * 2 + (swave & 1);           // MFMA lane of tile (row swave & 1, column w_t16)
+    const int v_lane = (cg >> 1) * VH_FLOATS + (lk * 32 + v_slot) * 4 + 2 * (cg & 1) + w_kpl;      // + xi * 256 (+ stage)
+    float patch[16];
+    constexpr int pcol[4] = {0, PLANAR ? 2 : 1, PLANAR ? 1 : 2, 3};                  // register position of patch column c
+    auto read_patch = [&]() __attribute__((always_inline)) {
+        const float *const xrp = xr - w_t16;                                        // column pairs (t16, t16 + 1) of both halves
+        if (PLANAR) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                patch[4 * r] = xrp[r * XP]; patch[4 * r + 1] = xrp[r * XP + 1];
+                patch[4 * r + 2] = xrp[r * XP + 20]; patch[4 * r + 3] = xrp[r * XP + 21];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x2 lo = *reinterpret_cast<const f32x2 *>(xr + r * XP), hi = *reinterpret_cast<const f32x2 *>(xr + r * XP + 2);
+                patch[4 * r] = lo[0]; patch[4 * r + 1] = lo[1]; patch[4 * r + 2] = hi[0]; patch[4 * r + 3] = hi[1];
+            }
+        }
+    };
+    // B^T d B of the lane's 4x4 patch into V stage `par`
+    auto transform_patch = [&](int par) __attribute__((always_inline)) {
+        float tt[16];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            tt[0 + x] = patch[0 + x] - patch[8 + x];
+            tt[4 + x] = patch[4 + x] + patch[8 + x];
+            tt[8 + x] = patch[8 + x] - patch[4 + x];
+            tt[12 + x] = patch[4 + x] - patch[12 + x];
+        }
+        float *vdst = lds + par * V_FLOATS + v_lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rs = row_slot(i);
+            vdst[(rs * 4 + 0) * 256] = tt[i * 4 + pcol[0]] - tt[i * 4 + pcol[2]];
+            vdst[(rs * 4 + 1) * 256] = tt[i * 4 + pcol[1]] + tt[i * 4 + pcol[2]];
+            vdst[(rs * 4 + 2) * 256] = tt[i * 4 + pcol[2]] - tt[i * 4 + pcol[1]];
+            vdst[(rs * 4 + 3) * 256] = tt[i * 4 + pcol[1]] - tt[i * 4 + pcol[3]];
+        }
+    };
+    const int u_voff = ((((8 * ih) * 2 + (hq & 1)) * 2 + lk) * 32 + l31) * 16;        // bytes; + e * 2048 + (8-channel chunk, 64-cout tile) image
+    const int b_off = (((8 * ih) * 2 + lk) * 32 + l31) * 4;                           // floats; + e * 256 (+ stage)
+    int w_co = 0;
+    // q8 = 8-channel chunk (2 * chunk + sub-chunk)
+    auto issue_u = [&](int e, int q8) __attribute__((always_inline)) {
+        const int w_soff = (q8 * 2 * a.co_tiles + 2 * w_co + (hq >> 1)) * (U_CHUNK_FLOATS * 4) + e * 2048;
+        ua[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, u_voff, w_soff, 0));
+    };
+
+    // ---------------------------------------------------------------- prologue: tile 0, chunk 0 staged, chunk 1 in flight
+    describe(0);
+    a_vm = g_vm; a_vmp = g_vmp; a_lsh = g_lsh; a_bord = g_bord;
+    w_co = g_co;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) issue_u(e, 0);
+    issue_raw(0);
+    if (ih == 0) fetch_bias(g_co * BN);
+    activate();
+    issue_raw(1);
+    read_patch();
+    transform_patch(0);
+    __syncthreads();
+
+    int s = 0;                                             // running chunk index (V stage parity)
+    int k = 0;
+    const bool stamp = IPDM_CONV_STAMPS && (a.dbg & 8) != 0;
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;      // stage / multiply / transform / barrier / epilogue
+    const unsigned long long st_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
+#define IPDM_STAMP(slot) if (stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[slot] += now_ - st_t; st_t = now_; __builtin_amdgcn_sched_barrier(0); }
+    if (stamp) st_t = st_begin;
+    TileId cur = {g_n, g_oy, g_ox, g_co * BN};
+    // One chunk: stage chunk s + 1 (activation -> scratch -> patch), multiply chunk s, transform chunk s + 1 into the other V
+    // stage, barrier.  The first chunk of a tile STARTS its accumulators (C = 0 in the first MFMA of each), so that they are
+    // dead from the output transform to the next tile.
+    auto chunk = [&](auto first, int ch) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first)::value;
+        const bool more1 = s + 1 < S;
+        const int ch1 = ch + 1 == nchunks ? 0 : ch + 1, ch2 = ch1 + 1 == nchunks ? 0 : ch1 + 1;
+        if (more1) {
+            if (ch == nchunks - 1) { a_vm = g_vm; a_vmp = g_vmp; a_lsh = g_lsh; a_bord = g_bord; }      // chunk s + 1 opens the tile described last
+            activate();                                    // raw(s + 1) -> scratch
+        }
+        if (ch == nchunks - 2 && k + 1 < n_my) describe(k + 1);      // before the first loads of the next tile
+        issue_raw(ch2);                                    // raw(s + 2), consumed one iteration from now
+        IPDM_STAMP(0)
+        const float *stage = lds + (s & 1) * V_FLOATS;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {                   // the two 8-channel sub-chunks of the staged chunk
+            const float *vh = stage + kc * VH_FLOATS;
+            f32x4 b_c = *reinterpret_cast<const f32x4 *>(vh + b_off), b_n;
+            if (kc == 1) {
+                read_patch();                              // patch(s + 1) (behind the first operand: the LDS returns in order)
+                if (ch1 == 0) w_co = g_co;                 // from here on the weights loaded belong to the tile described last
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e + 1 < 8) b_n = *reinterpret_cast<const f32x4 *>(vh + b_off + (e + 1) * 256);
+                if (FIRST && kc == 0) {
+                    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e][0], b_c[0], zero, 0, 0, 0);
+                } else {
+                    acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e][0], b_c[0], acc[e], 0, 0, 0);
+                }
+#pragma unroll
+                for (int qq = 1; qq < 4; ++qq) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e][qq], b_c[qq], acc[e], 0, 0, 0);
+                // the U of this position for the NEXT sub-chunk, into the registers just read
+                issue_u(e, kc == 0 ? 2 * ch + 1 : 2 * ch1);
+                if (e + 1 < 8) b_c = b_n;
+            }
+        }
+        IPDM_STAMP(1)
+        transform_patch((s + 1) & 1);                      // V(s + 1); that stage was last read by chunk s - 1
+        IPDM_STAMP(2)
+        __syncthreads();                                   // V(s + 1) complete; every wave is done with V(s)
+        IPDM_STAMP(3)
+        ++s;
+    };
+    for (; k < n_my; ++k) {
+        chunk(std::true_type{}, 0);
+        for (int ch = 1; ch < nchunks; ++ch) chunk(std::false_type{}, ch);
+        // ---------------------------------------------------------------- tile epilogue
+        // + bias through position (1, 1) (accumulator 5 of the ih = 0 waves), whose output coefficients are all 1
+        if (ih == 0) {
+            acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb, 1.0f, acc[5], 0, 0, 0);
+            if (k + 1 < n_my) fetch_bias(g_co * BN);        // (describe(k + 1) ran two chunks ago)
+        }
+        const TileId t = cur;
+        cur = TileId{g_n, g_oy, g_ox, g_co * BN};
+        const size_t sample = (size_t)t.n * a.Cout * out_plane;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * out_plane * 4, 0x00020000);
+        // (no residual: zero records -- the loads below return 0 and the add stays unconditional)
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0,
+                                                                                   a.res ? a.Cout * out_plane * 4 : 0, 0x00020000);
+        // The lanes l and l + 16 (tile columns 2m, 2m + 1) hold 4 consecutive pixels of the row between them.  Registers are
+        // taken in pairs (couts c, c + 1): v_permlane16_swap exchanges one half each, after which the lane of the even column
+        // owns the 4 pixels of cout c and the other one those of cout c + 1 -- 16-byte stores and residual loads.
+        const int py = t.oy0 + 2 * ty + ih, px4 = t.ox0 + 4 * txh;
+        const bool rok = py < a.Ho;
+        const int lane_off4 = ((lk * 4 + odd) * out_plane + (2 * ty + ih) * a.Wo + 4 * txh) * 4;
+        const int voff4 = (rok && px4 + 3 < a.Wo) ? lane_off4 : OOB;             // all four pixels of the lane's run
+        const bool ragged = t.ox0 + TW > a.Wo && (a.Wo & 3) != 0;                // (wave-uniform) a run straddles the right edge
+        const bool clipped = t.oy0 + TH > a.Ho || t.ox0 + TW > a.Wo;             // (wave-uniform) some lanes own no pixels
+        const int nval = a.Wo - px4;                                              // ... then it has 1..3 pixels
+        const bool part = ragged && rok && nval > 0 && nval < 4;
+        const int so0 = ((t.co0 + hq * 32) * out_plane + min(t.oy0, a.Ho - 1) * a.Wo + t.ox0) * 4;
+        const float *xr2 = xch + ((swave ^ 1) * 8) * 256 + lane * 4;
+        float *sb = xw;                                      // statistics staging: the wave's scratch is idle here
+        const f32x2 sgn2 = {sgn, sgn};
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        // ALL residual loads of the tile are issued together, ahead of the transform
+        f32x4 rv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4, so0 + (8 * (i >> 1) + 2 * (i & 1)) * plane4, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        // columns first (in-lane): T_i[b] = sum_j M[i][j] A[j][b],  A^T = [[1,1,1,0],[0,1,-1,-1]]; then the wave's own two
+        // rows (first = accumulators 0-3, second = 4-7; ih = 0: rows 0, 1, ih = 1: rows 3, 2 -- row_slot): both waves keep
+        // K = first + second and send the second (T1 resp. T2); output row 0 = (T0 + T1) + T2, row 1 = T1 - (T2 + T3).
+        f32x2 K0[8], K1[8];                                 // [pair]: output column 0 / 1 of {cout c, cout c + 1}
+        {
+            float *xo = xch + (swave * 8) * 256 + lane * 4;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int r = 2 * p;
+#define IPDM_M(e) f32x2{acc[e][r], acc[e][r + 1]}
+                const f32x2 lo0 = (IPDM_M(0) + IPDM_M(1)) + IPDM_M(2), lo1 = (IPDM_M(1) - IPDM_M(2)) - IPDM_M(3);
+                const f32x2 hi0 = (IPDM_M(4) + IPDM_M(5)) + IPDM_M(6), hi1 = (IPDM_M(5) - IPDM_M(6)) - IPDM_M(7);
+#undef IPDM_M
+                K0[p] = lo0 + hi0;
+                K1[p] = lo1 + hi1;
+                *reinterpret_cast<f32x4 *>(xo + p * 256) = f32x4{hi0[0], hi0[1], hi1[0], hi1[1]};
+            }
+        }
+        __syncthreads();                                   // E: both halves of every (tile, cout) are in LDS
+        f32x4 gotv[8];                                     // partner's {T[0] c, T[0] c+1, T[1] c, T[1] c+1} of every pair
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gotv[i] = *reinterpret_cast<const f32x4 *>(xr2 + i * 256);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = i >> 1, u = 2 * (i & 1);
+            const f32x4 got = gotv[i];
+            // ih = 0: K + T2 (output row 0);  ih = 1: T1 - K (output row 1)
+            const f32x2 y0 = __builtin_elementwise_fma(K0[i], sgn2, f32x2{got[0], got[1]});       // column 0 of {cout c, c + 1}
+            const f32x2 y1 = __builtin_elementwise_fma(K1[i], sgn2, f32x2{got[2], got[3]});       // column 1
+            // rows r (even tile column) and r + 1 (odd) of the DPP row pair: the even one gives its cout c + 1 and takes the
+            // odd one's cout c  (inline asm: through the builtin this compiler passed component 0 of y0 / y1 as BOTH operands
+            // of the swap; s_nop: the swap reads need two wait states after the VALU writes)
+            float ya0 = y0[0], yb0 = y0[1], ya1 = y1[0], yb1 = y1[1];
+            asm("s_nop 1\n\t"
+                "v_permlane16_swap_b32 %0, %1\n\t"
+                "v_permlane16_swap_b32 %2, %3"
+                : "+v"(ya0), "+v"(yb0), "+v"(ya1), "+v"(yb1));
+            f32x4 v = {ya0, ya1, yb0, yb1};
+            const int so = so0 + (8 * g + u) * plane4;
+            v += rv[i];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4, so, 0);
+            if (ragged) {            // (wave-uniform) the run that straddles the edge: element by element, by its lane
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int vo1 = (part && e < nval) ? lane_off4 + 4 * e : OOB;
+                    float x = v[e];
+                    if (a.res) x += bload(r_rsrc, vo1, so);        // (the lane's 16-byte residual load was out of range: + 0 above)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), o_rsrc, vo1, so, 0);
+                    if (part) v[e] = e < nval ? x : 0.0f;
+                }
+            }
+            if (a.stats) {
+                // fused GroupNorm statistics of the output: one row of per-cout {sum, sum of squares} per PIXEL ROW and
+                // 32-pixel column block, as conv_ws.hip writes them; the 8 lanes of one tile row in a DPP row share a cout
+                float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                float s2 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+                if (clipped) {
+                    const bool ok = voff4 != OOB || part;
+                    s1 = ok ? s1 : 0.0f; s2 = ok ? s2 : 0.0f;
+                }
+                asm("s_nop 1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                    "s_nop 0\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                    "s_nop 0\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf"
+                    : "+v"(s1), "+v"(s2));
+                if (txh == 0) *reinterpret_cast<f32x2 *>(sb + (ty * 32 + 8 * g + u + odd + 4 * lk) * 2) = f32x2{s1, s2};
+            }
+        }
+        if (a.stats) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int row_y = t.oy0 + 2 * lk + ih;          // lanes 0-31: tile row 0, lanes 32-63: tile row 1; cout = l31
+            if (row_y < a.Ho) {
+                float *dst = a.stats + (((size_t)t.n * a.stats_rows + (size_t)row_y * a.tiles_x + t.ox0 / TW) * a.Cout + t.co0 + hq * 32 + l31) * 2;
+                *reinterpret_cast<f32x2 *>(dst) = *reinterpret_cast<const f32x2 *>(sb + lane * 2);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        IPDM_STAMP(4)
+    }
+    if (stamp && tid == 0) {
+        unsigned long long *d = a.dbg_buf + (size_t)blockIdx.x * 8;
+        d[0] = st_acc[1]; d[1] = st_acc[4]; d[2] = st_acc[3]; d[3] = __builtin_amdgcn_s_memtime() - st_begin;
+        d[4] = st_acc[0]; d[5] = st_acc[2]; d[6] = 0; d[7] = 0;
+    }
+#undef IPDM_STAMP
+}
+
+}  // namespace
+
+namespace ipdm {
+
+// Both Winograd kernels accumulate a (tile, cout) in the same order -- 8-channel sub-chunks ascending, four k steps each, the
+// same output transform -- so their results are bit-identical (tests/test_gpu_parity.py::test_wino_kernels_bit_identical) and
+// the choice may look at the batch: launches whose 128-cout tiles would leave a quarter of the chip idle (a lone slice on the
+// mid-resolution levels: 256->256 @64x64 is 64 tiles, 0.64x the round-3 kernel's time on its 128) stay on the 64-cout tiles.
+bool conv_wino2_eligible(const ConvArgs &a)
+{
+    const int Ctot = a.C1 + a.C2;
+    if (a.Cout % BN || Ctot % KC || (a.C2 && a.C1 % KC) || Ctot < 2 * KC) return false;
+    const long ntiles = (long)cdiv(a.Ho, TH) * cdiv(a.Wo, TW) * (a.Cout / BN) * a.B;
+    return ntiles >= opt(OPT_WINO2_MIN_TILES);      // (192; a per-call option so that tests can drive small shapes through this kernel)
+}
+
+// `a`: the arguments as conv2d_wino_launch prepared them (a.w = the Winograd-domain weights, tiles_x / tiles_y for 4 x 32-pixel
+// tiles), conv_wino2_eligible(a)
+int conv2d_wino2_launch(const ConvArgs &prepared, hipStream_t st)
+{
+    ConvArgs a = prepared;
+    a.co_tiles = a.Cout / BN;
+    const long ntiles = (long)a.tiles_x * a.tiles_y * a.co_tiles * a.B;
+    const int cus = device_cu_count();
+    long G = ntiles < cus ? ntiles : cus;
+    G = (G + 7) / 8 * 8;
+    const void *fn = a.x1_planar ? (const void *)conv_wino2_kernel<true> : (const void *)conv_wino2_kernel<false>;
+    if (int rc = ensure_dynamic_lds(fn, LDS_BYTES)) return rc;
+    if (a.x1_planar) hipLaunchKernelGGL(conv_wino2_kernel<true>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    else hipLaunchKernelGGL(conv_wino2_kernel<false>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    return IPDM_OK;
+}
+
+}  // namespace ipdm

@@ -1375,6 +1375,25 @@ extern "C" int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t st
     return conv_weight_interleave(Cout, ksize, stride);
 }
 
+extern "C" int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W)
+{
+    if (B <= 0 || Cout <= 0 || Cin <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3) || stride < 1 || stride > 2) return -1;
+    static float dummy;                    // (only tested for null by the eligibility rules)
+    const int pad = ksize / 2;
+    ConvArgs a;
+    a.x1 = &dummy; a.x2 = nullptr; a.C1 = Cin; a.C2 = 0; a.B = B; a.Hs = H; a.Ws = W; a.H = H; a.W = W; a.upsample = 0;
+    a.scale_y = a.scale_x = 1.f; a.w = &dummy; a.bias = nullptr; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
+    a.w_interleave = conv_weight_interleave(Cout, ksize, stride);
+    const int group = conv_sx_pieces(a.w_interleave) ? 64 : (a.w_interleave ? 32 * a.w_interleave : 64);      // (conv_pack_weights)
+    a.cout_pad = (Cout + group - 1) / group * group;
+    a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
+    a.act = 0; a.gn_scale = a.gn_shift = nullptr; a.res = nullptr; a.out = &dummy;
+    a.tiles_x = a.tiles_y = a.co_tiles = 0;
+    a.w_wino = conv_wino_shape_ok(Cout, Cin, ksize, stride, a.w_interleave) ? &dummy : nullptr;
+    a.split_ws = &dummy;
+    return conv_kernel_code(a);
+}
+
 extern "C" int ipdm_bench_attention(int32_t B, int32_t heads, int32_t d, int32_t T, int32_t iters, float *avg_ms)
 {
     IPDM_REQUIRE(avg_ms && iters > 0, "bench_attention: bad argument");

@@ -58,6 +58,7 @@ struct ConvArgs {
 };
 
 int conv2d_launch(const ConvArgs &a, hipStream_t st);
+int conv_kernel_code(const ConvArgs &a);                  // which kernel conv2d_launch would take (codes: include/ipdm_hip.h)
 int conv2d_ws_launch(const ConvArgs &a, hipStream_t st);   // persistent wave-specialised variant (conv_ws.hip)
 // opt-in split-bf16 evaluation of the wide 3x3 convolutions (conv_sx.hip); weight layout code 100 + pieces
 int conv_sx_pieces(int interleave);
@@ -120,6 +121,8 @@ bool conv_up2_eligible(const ConvArgs &a);         // shape fields + w_up2 + w_i
 bool conv_wino_eligible(const ConvArgs &a);        // shape fields + w_wino decide
 bool conv_wino_shape_ok(int Cout, int Cin, int ks, int stride, int interleave);   // worth packing U for this layer
 int conv2d_wino_launch(const ConvArgs &a, hipStream_t st);
+bool conv_wino2_eligible(const ConvArgs &a);       // ... of those, the layers the round-4 kernel takes (whole 128-cout tiles, 16-channel chunks)
+int conv2d_wino2_launch(const ConvArgs &prepared, hipStream_t st);   // conv_wino2.hip; called by conv2d_wino_launch
 // [Cin/8][Cout/64][xi 16][cout half][k parity][cout 32][k step] = the LDS image of one (chunk, cout tile)
 void conv_pack_weights_wino(const float *w, int Cout, int Cin, std::vector<float> &packed);
 bool conv_ws_planar_ok(const ConvArgs &a);

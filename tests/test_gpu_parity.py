@@ -494,7 +494,7 @@ def test_reference_blocks_golden(golden):
         np.testing.assert_allclose(y.cpu().numpy(), g[tag + "_out"], rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize("case", [
+STATS_CHAIN_CASES = [
     # B, C, H, W, CA, ksA, strideA, resA, act, CB        (conv A's kernel family decides the statistics geometry)
     (2, 64, 48, 64, 128, 3, 1, True, 2, 64),      # conv_ws 8x32x128 tiles, 16-byte epilogue, residual
     (2, 64, 40, 36, 64, 3, 1, False, 2, 64),      # conv_ws 16x32x64 tiles, ragged right edge and bottom (masked lanes)
@@ -514,8 +514,10 @@ def test_reference_blocks_golden(golden):
     (2, 16, 30, 44, 4, 1, 1, False, 1, 4),        # narrow 1x1
     (1, 48, 20, 24, 24, 3, 1, False, 2, 24),      # 16 < couts <= 32: the 4-wave kernel of conv.hip
     (2, 8, 37, 61, 8, 3, 2, False, 2, 8),         # narrow stride-2 (Downsample of the 4/8/16-channel levels): 4-wave kernel, ragged tiles
-])
-def test_fused_groupnorm_statistics_chain(case):
+]
+
+
+def _conv_gn_conv(case):
     """conv A -> GroupNorm(+SiLU) -> conv B where the GroupNorm statistics come from the per-tile partial sums conv A's
     epilogue wrote (ConvArgs::stats -> gn_tile_reduce -> gn_finalize), for every producing kernel family, against
     torch ops (fp32): 2e-5 relative like the single-convolution tests."""
@@ -554,6 +556,113 @@ def test_fused_groupnorm_statistics_chain(case):
     assert (d_mid.cpu() - mid).abs().max() <= 2e-5 * max(1.0, mid.abs().max().item())
     err = (d_out.cpu() - want).abs().max().item()
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
+    return d_mid.cpu(), d_out.cpu(), rows.value
+
+
+@pytest.mark.parametrize("case", STATS_CHAIN_CASES)
+def test_fused_groupnorm_statistics_chain(case):
+    _conv_gn_conv(case)
+
+
+def test_conv_kernel_code_table():
+    """ipdm_conv_kernel_code names the kernel a shape takes NOW (include/ipdm_hip.h): the production layers land where
+    DESIGN section 3 says they do, so a parity case that believes it covers a kernel can assert it."""
+    from ipdm_pytorch_amd import _lib
+    code = _lib.lib().ipdm_conv_kernel_code
+    table = [
+        # B, Cout, Cin, ks, stride, H, W -> code
+        ((8, 128, 128, 3, 1, 512, 512), 2),      # wide 3x3: Winograd, 128-cout tiles
+        ((8, 256, 384, 3, 1, 114, 250), 2),
+        ((1, 128, 128, 3, 1, 512, 512), 2),      # a lone slice still fills the chip at 512x512
+        ((1, 256, 256, 3, 1, 64, 64), 1),        # ... not at 64x64: the 64-cout tiles (bit-identical results)
+        ((8, 64, 64, 3, 1, 512, 512), 1),        # 64-cout layers: no 128-cout tile
+        ((8, 128, 144, 3, 1, 228, 500), 2),      # 128 + 16 concat of the proj UNet
+        ((8, 128, 72, 3, 1, 228, 500), 1),       # Cin not a multiple of 16
+        ((8, 256, 256, 3, 1, 32, 32), 4),        # K-split layer (direct kernel + combine)
+        ((8, 768, 256, 1, 1, 64, 64), 3),        # qkv 1x1
+        ((8, 128, 128, 3, 2, 512, 512), 3),      # Downsample
+        ((8, 8, 8, 3, 1, 2000, 912), 5),         # narrow level
+        ((1, 24, 48, 3, 1, 20, 24), 8),          # 16 < Cout <= 32: the generic 4-wave kernel
+    ]
+    for args, want in table:
+        assert code(*args) == want, (args, code(*args), want)
+    with _lib.option("wino_v1", 1):
+        assert code(8, 128, 128, 3, 1, 512, 512) == 1
+    with _lib.option("conv_no_wino", 1):
+        assert code(8, 128, 128, 3, 1, 512, 512) == 3
+    assert code(0, 128, 128, 3, 1, 8, 8) == -1
+
+
+WINO128_CASES = [
+    # B, C1, C2, H, W, Cout, act, res       (3x3 stride 1; whole 128-cout tiles, 16-channel chunks, more than 16 direct tiles
+    #                                        per sample -- fewer are K-split layers, which stay on the direct kernel)
+    (1, 128, 0, 72, 64, 128, 0, False),      # no prologue, no residual
+    (2, 128, 0, 37, 145, 128, 2, True),      # ragged both ways, odd width (the partial-run epilogue)
+    (1, 128, 128, 24, 70, 256, 2, False),    # concat, two cout tiles, width % 4 == 2
+    (2, 64, 64, 45, 95, 128, 1, True),       # concat at a 64-channel boundary, width % 4 == 3
+    (1, 256, 0, 17, 125, 256, 2, True),      # width % 4 == 1, 16 chunks
+    (1, 32, 0, 33, 97, 128, 2, False),       # two chunks (the minimum)
+    (3, 128, 16, 40, 104, 128, 2, True),     # concat with a 16-channel skip (proj UNet: 128 + 16 -> 128)
+    (1, 128, 0, 130, 250, 128, 2, True),     # many tiles per workgroup, several rounds
+]
+
+
+@pytest.mark.parametrize("case", WINO128_CASES)
+def test_wino_kernels_bit_identical(case):
+    """The two Winograd kernels (round-3 64-cout tiles / round-4 128-cout tiles, conv_wino2.hip) accumulate every output in
+    the same order, so the launcher may choose between them by the batch: their outputs must agree BIT FOR BIT, and both
+    must sit within the usual 2e-5 of the fp32 torch op."""
+    from ipdm_pytorch_amd import _lib
+    import torch.nn.functional as F
+    B, C1, C2, H, W, Cout, act, res = case
+    seed = 8800 + sum(case[:6])
+    Cin = C1 + C2
+    x1 = torch.from_numpy(synth.hash_normal((B, C1, H, W), seed))
+    x2 = torch.from_numpy(synth.hash_normal((B, C2, H, W), seed + 1)) * 2 + 0.5 if C2 else None
+    w = torch.from_numpy(synth.hash_normal((Cout, Cin, 3, 3), seed + 2)) / np.sqrt(Cin * 9)
+    bias = torch.from_numpy(synth.hash_normal((Cout,), seed + 3))
+    gamma = torch.from_numpy(synth.hash_uniform((Cin,), seed + 4)) + 0.5
+    beta = torch.from_numpy(synth.hash_normal((Cin,), seed + 5)) * 0.2
+    groups = ou.gn_groups(Cin)
+    h = x1 if x2 is None else torch.cat([x1, x2], 1)
+    if act:
+        h = F.group_norm(h, groups, gamma, beta, eps=1e-5)
+        if act == 2:
+            h = F.silu(h)
+    want = F.conv2d(h, w, bias, padding=1)
+    r = torch.from_numpy(synth.hash_normal(tuple(want.shape), seed + 6)) if res else None
+    if res:
+        want = want + r
+    x1d, x2d, rd = x1.to(DEV), (x2.to(DEV) if C2 else None), (r.to(DEV) if res else None)
+    wn, bn, gn_, ben = (np.ascontiguousarray(t.numpy()) for t in (w, bias, gamma, beta))
+    outs = []
+    for v1 in (1, 0):
+        out = torch.full(tuple(want.shape), float("nan"), device=DEV)
+        with _lib.option("wino_v1", v1), _lib.option("wino2_min_tiles", 1):
+            code = _lib.lib().ipdm_conv_kernel_code(B, Cout, Cin, 3, 1, H, W)
+            assert code == (1 if v1 else 2), code           # 1: conv_wino (64-cout tiles), 2: conv_wino2 (128-cout tiles)
+            _lib.call("ipdm_op_conv2d", _lib.ptr(x1d), C1, _lib.ptr(x2d), C2, B, H, W, H, W, _lib.ptr(wn), _lib.ptr(bn), Cout, 3, 1,
+                      act, groups, _lib.ptr(gn_), _lib.ptr(ben), _lib.ptr(rd), _lib.ptr(out), _lib.current_stream())
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max()
+    err = (outs[1] - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
+
+
+def test_wino128_fused_statistics_and_planar_reader():
+    """conv_wino2 as the PRODUCER of fused GroupNorm statistics (conv A -> GroupNorm+SiLU -> conv B: d_mid, the rows and the
+    result bit-equal to the 64-cout kernel's) and as the READER of a parity-planar x1 (the up2 -> concat -> conv chain)."""
+    from ipdm_pytorch_amd import _lib
+    for case in [(2, 64, 48, 64, 128, 3, 1, True, 2, 128), (1, 128, 21, 57, 256, 3, 1, True, 2, 128), (2, 128, 26, 250, 128, 3, 1, True, 2, 128)]:
+        res = []
+        for v1 in (1, 0):
+            with _lib.option("wino_v1", v1), _lib.option("wino2_min_tiles", 1):
+                res.append(_conv_gn_conv(case))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2], case
+    with _lib.option("wino2_min_tiles", 1):
+        for case in UP2_CASES:
+            if case[6] % 128 == 0 and case[7] == 3:
+                test_upsample_conv_parity_form(case)
 
 
 def test_k_split_layers_on_the_winograd_kernel_opt_in():
@@ -631,7 +740,7 @@ def test_fused_groupnorm_statistics_with_a_large_channel_offset(offset):
     assert err <= budget, (err, budget, ratio)
 
 
-@pytest.mark.parametrize("case", [
+UP2_CASES = [
     # B, C, Hs, Ws, CA, C2, CB, ksB, act
     (2, 128, 16, 32, 128, 0, 128, 3, 2),          # 128-cout tiles; GroupNorm from the parity form's fused statistics
     (1, 64, 13, 21, 64, 64, 64, 3, 2),            # 64-cout tiles, odd source size (ragged tiles in every parity), concat with a skip
@@ -647,7 +756,10 @@ def test_fused_groupnorm_statistics_with_a_large_channel_offset(offset):
     (1, 128, 40, 72, 128, 64, 128, 3, 2),         # Winograd-domain reader of a parity-planar source, concatenated skip (80x144)
     (2, 64, 33, 47, 64, 0, 64, 3, 2),             # ... ragged tiles on both axes (66x94), border tiles on all sides
     (1, 64, 34, 50, 64, 64, 64, 3, 1),            # ... GroupNorm without SiLU, 68x100
-])
+]
+
+
+@pytest.mark.parametrize("case", UP2_CASES)
 def test_upsample_conv_parity_form(case):
     """Upsample (nearest 2x + 3x3 conv) evaluated as four 2x2-tap convolutions over the source grid (the taps that fall on
     one source pixel added up when the weights are packed; on narrow levels inside the direct kernel), its parity-planar output, the fused statistics of that output

@@ -41,9 +41,11 @@ def run(B, C1, C2, H, W, Cout, act, res, seed=1):
     outs = {}
     x1d, x2d, rd = x1.to(DEV), (x2.to(DEV) if C2 else None), (r.to(DEV) if res else None)      # (kept alive across the calls)
     wn, bn, gn_, ben = (np.ascontiguousarray(t.numpy()) for t in (w, bias, gamma, beta))
+    codes = {}
     for mode in (0, 1):
         out = torch.full((B, Cout, H, W), float("nan"), device=DEV)
         with _lib.option("conv_no_wino", mode):
+            codes[mode] = _lib.lib().ipdm_conv_kernel_code(B, Cout, Cin, 3, 1, H, W)      # (1 / 2: Winograd 64- / 128-cout tiles, 3 / 4: direct)
             _lib.call("ipdm_op_conv2d", _lib.ptr(x1d), C1, _lib.ptr(x2d), C2, B, H, W, H, W, _lib.ptr(wn), _lib.ptr(bn), Cout, 3, 1,
                       act, groups, _lib.ptr(gn_), _lib.ptr(ben), _lib.ptr(rd), _lib.ptr(out), _lib.current_stream())
         torch.cuda.synchronize()
@@ -56,8 +58,8 @@ def run(B, C1, C2, H, W, Cout, act, res, seed=1):
     (wm, wr), (dm, dr), (tm, tr) = d(outs[0]), d(outs[1]), d(w32)
     bad = int(torch.isnan(outs[0]).sum())
     print("B%d %d+%d->%d @%dx%d act%d res%d | wino max %.2e rms %.2e | direct max %.2e rms %.2e | torch32 max %.2e rms %.2e | "
-          "wino/direct rms %.2f  rel-max %.1e nan %d" % (B, C1, C2, Cout, H, W, act, int(res), wm, wr, dm, dr, tm, tr, wr / max(dr, 1e-30),
-                                                       wm / sc, bad), flush=True)
+          "wino/direct rms %.2f  rel-max %.1e nan %d  kernels %d/%d%s" % (B, C1, C2, Cout, H, W, act, int(res), wm, wr, dm, dr, tm, tr, wr / max(dr, 1e-30),
+                                                       wm / sc, bad, codes[0], codes[1], "" if codes[0] in (1, 2) else "  (NOT Winograd: this shape falls back)"), flush=True)
     return wm / sc
 
 
@@ -65,16 +67,17 @@ def bench(B, C1, C2, H, W, Cout, act, res, iters=20, planar=False):
     act = act | (256 if planar else 0)
     ms = {}
     for rep in range(2):
-        for mode in (0, 1):
+        for mode in (0, 1, 2):          # 0: Winograd (round-4 kernel), 1: direct conv_ws, 2: Winograd, round-3 kernel
             t = C.c_float()
-            with _lib.option("conv_no_wino", mode):
+            with _lib.option("conv_no_wino", int(mode == 1)), _lib.option("wino_v1", int(mode == 2)):
                 _lib.call("ipdm_bench_conv2d", B, C1, C2, H, W, Cout, 3, 1, act, int(res), iters, C.byref(t))
             ms.setdefault(mode, []).append(t.value)
     fl = 2.0 * B * H * W * Cout * (C1 + C2) * 9
-    a, b = min(ms[0]), min(ms[1])
+    a, b, v1 = min(ms[0]), min(ms[1]), min(ms[2])
     act &= 255
-    print(("planar " if planar else "") + "bench B%d %d+%d->%d @%dx%d act%d res%d: wino %.3f ms (%.1f TF/s-equivalent) direct %.3f ms (%.1f TF/s)  speedup %.2fx" % (
-        B, C1, C2, Cout, H, W, act, int(res), a, fl / a / 1e9, b, fl / b / 1e9, b / a), flush=True)
+    print(("planar " if planar else "") + "bench B%d %d+%d->%d @%dx%d act%d res%d: wino %.3f ms (%.1f TF/s-equivalent, %.3f of the f32 peak executed) "
+          "r03 kernel %.3f ms (%.2fx) direct %.3f ms (%.1f TF/s)  speedup %.2fx" % (
+        B, C1, C2, Cout, H, W, act, int(res), a, fl / a / 1e9, fl * 16 / 36 / a / 1e9 / 157.3, v1, v1 / a, b, fl / b / 1e9, b / a), flush=True)
 
 
 def main():
@@ -106,6 +109,11 @@ def main():
     bench(8, 128, 0, 512, 512, 128, 2, True)
     if quick:
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        for B in (1, 2, 4, 8):
+            for shp in ((128, 128, 128), (256, 128, 128), (256, 64, 64), (128, 250, 114), (256, 125, 57), (256, 250, 114)):
+                bench(B, shp[0], 0, shp[1], shp[2], shp[0], 2, True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "planar":
         for pl in (False, True):
             bench(8, 64, 64, 512, 512, 64, 2, False, planar=pl)
@@ -119,8 +127,17 @@ def main():
     bench(8, 128, 0, 228, 500, 128, 2, True)
     bench(8, 256, 0, 114, 250, 256, 2, True)
     bench(8, 256, 128, 114, 250, 256, 2, False)
+    bench(8, 256, 0, 64, 64, 256, 2, True)
+    bench(8, 128, 0, 128, 128, 128, 2, True)
+    bench(8, 256, 0, 125, 57, 256, 2, True)
     bench(1, 128, 0, 512, 512, 128, 2, True)
+    bench(1, 128, 0, 256, 256, 128, 2, True)
+    bench(1, 128, 0, 128, 128, 128, 2, True)
+    bench(1, 256, 0, 128, 128, 256, 2, True)
     bench(1, 256, 0, 64, 64, 256, 2, True)
+    bench(1, 128, 0, 500, 228, 128, 2, True)
+    bench(1, 128, 0, 250, 114, 128, 2, True)
+    bench(1, 256, 0, 125, 57, 256, 2, True)
 
 
 if __name__ == "__main__":
