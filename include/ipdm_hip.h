@@ -31,7 +31,7 @@ extern "C" {
 #define IPDM_ERR_UNSUPPORTED (-4)
 
 const char *ipdm_last_error(void);
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any signature change): 2. */
 int ipdm_abi_version(void);
 
 /* Process-wide switches of the library (A/B experiments, opt-in evaluation modes); no reference counterpart -- the
@@ -259,10 +259,13 @@ int ipdm_art_project(ipdm_art_plan *plan, const float *d_volume, float *d_proj, 
  * reference counterpart -- the reference has no profiling).  Classes: 0 = conv 3x3
  * stride-1 wide tile in its direct form, 1 = other conv variants, 2 = attention, 3 = the Winograd-domain form of
  * class 0's layers (recorded with its EXECUTED flops, 16/36 of the 3x3 count), 4 = the narrow direct convolutions
- * (bandwidth-bound: `out_flops[4]` holds their algorithmic HBM BYTES).  ipdm_profile_end needs the stream
- * synchronised; outputs are arrays of 5. */
+ * (bandwidth-bound: `out_flops[4]` holds their algorithmic HBM BYTES), 5 = the 128-cout-tile Winograd kernel
+ * (conv_wino2, the dominant kernel; class 3 keeps the 64-cout-tile one).  ipdm_profile_end needs the stream
+ * synchronised; outputs are arrays of `n_classes` >= IPDM_PROF_CLASSES entries (a shorter array is an error, not an
+ * overflow). */
+#define IPDM_PROF_CLASSES 6
 int ipdm_profile_begin(int32_t max_launches);
-int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches);
+int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches, int32_t n_classes);
 
 /* kernel micro-benchmarks (tuning aid; allocate, fill with random data, time `iters` launches) */
 int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, int32_t W, int32_t Cout, int32_t ksize,

@@ -31,6 +31,9 @@ class UnetCfg(C.Structure):
 _vp, _i32, _i64, _u64, _f32, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); restype int => status code checked by _call
+ABI_VERSION = 2          # ipdm_abi_version() of the header these prototypes were written against
+PROF_CLASSES = 6         # kernel classes of ipdm_profile_end (include/ipdm_hip.h)
+
 PROTOTYPES = {
     "ipdm_last_error": (C.c_char_p, []),
     "ipdm_abi_version": (C.c_int, []),
@@ -78,7 +81,7 @@ PROTOTYPES = {
     "ipdm_op_up_conv_chain": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp,
                                         _i32, _i32, _vp, _vp, C.POINTER(_i32), _vp]),
     "ipdm_profile_begin": (C.c_int, [_i32]),
-    "ipdm_profile_end": (C.c_int, [C.POINTER(_f64 * 5), C.POINTER(_f64 * 5), C.POINTER(_i64 * 5)]),
+    "ipdm_profile_end": (C.c_int, [C.POINTER(_f64 * PROF_CLASSES), C.POINTER(_f64 * PROF_CLASSES), C.POINTER(_i64 * PROF_CLASSES), _i32]),
     "ipdm_bench_conv2d": (C.c_int, [_i32] * 11 + [C.POINTER(_f32)]),
     "ipdm_bench_attention": (C.c_int, [_i32] * 5 + [C.POINTER(_f32)]),
     "ipdm_op_attention": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -113,6 +116,10 @@ def lib():
             fn = getattr(handle, name)       # AttributeError => header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        got = handle.ipdm_abi_version()
+        if got != ABI_VERSION:
+            raise IpdmError("%s has ABI version %d, this package binds version %d (include/ipdm_hip.h): rebuild with "
+                            "__graft_entry__.build()" % (LIB_PATH, got, ABI_VERSION))
         _lib = handle
     return _lib
 

@@ -114,7 +114,7 @@ int device_cu_count()
 }  // namespace ipdm
 
 extern "C" const char *ipdm_last_error(void) { return ipdm::g_err; }
-extern "C" int ipdm_abi_version(void) { return 1; }
+extern "C" int ipdm_abi_version(void) { return 2; }      // 2: ipdm_profile_end takes its array length; ipdm_conv_kernel_code
 
 extern "C" int ipdm_set_option(const char *name, int value)
 {

@@ -782,14 +782,14 @@ int conv2d_wino_launch(const ConvArgs &args, hipStream_t st)
     G = (G + 7) / 8 * 8;
     const void *fn = a.x1_planar ? (const void *)conv_wino_kernel<true> : (const void *)conv_wino_kernel<false>;
     if (int rc = ensure_dynamic_lds(fn, LDS_BYTES)) return rc;
-    const bool prof = prof_enabled();
-    if (prof) prof_before(3, st);
-    if (!opt(OPT_WINO_V1) && conv_wino2_eligible(a)) {
+    const bool prof = prof_enabled(), v2 = !opt(OPT_WINO_V1) && conv_wino2_eligible(a);
+    if (prof) prof_before(v2 ? 5 : 3, st);
+    if (v2) {
         if (int rc = conv2d_wino2_launch(a, st)) return rc;
     } else if (a.x1_planar) hipLaunchKernelGGL(conv_wino_kernel<true>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
     else hipLaunchKernelGGL(conv_wino_kernel<false>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
     // EXECUTED flops: 16 multiply-adds per 2x2 output tile and (cin, cout) pair (the 3x3 form counts 36)
-    if (prof) prof_after(3, 2.0 * a.B * (double)cdiv(a.Ho, 2) * cdiv(a.Wo, 2) * 16.0 * a.Cout * (a.C1 + a.C2), st);
+    if (prof) prof_after(v2 ? 5 : 3, 2.0 * a.B * (double)cdiv(a.Ho, 2) * cdiv(a.Wo, 2) * 16.0 * a.Cout * (a.C1 + a.C2), st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }

@@ -38,6 +38,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef IPDM_WINO2_KO
+#define IPDM_WINO2_KO 0             // compile-time timing knock-outs (tools/build_variants.sh; results are WRONG under a knock-out):
+#endif                              // 1 no activation, 2 no input transform, 4 no output transform / stores, 8 no window loads, 16 no U loads
+#ifndef IPDM_WINO2_STAGGER
+#define IPDM_WINO2_STAGGER 0
+#endif
 #ifndef IPDM_CONV_STAMPS
 #define IPDM_CONV_STAMPS 0          // `make stamps`: in-kernel s_memtime stamps of the phases (a stamped build changes what it measures)
 #endif
@@ -372,16 +378,23 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     // One chunk: stage chunk s + 1 (activation -> scratch -> patch), multiply chunk s, transform chunk s + 1 into the other V
     // stage, barrier.  The first chunk of a tile STARTS its accumulators (C = 0 in the first MFMA of each), so that they are
     // dead from the output transform to the next tile.
+    // Waves w and w + 4 share a SIMD.  Both running the same program in lockstep would stage together (the matrix pipe idle)
+    // and then compete for it; waves 4-7 therefore do their staging BETWEEN the two sub-chunks, under their partners' MFMAs,
+    // and multiply while the partners stage at the chunk boundary (IPDM_WINO2_STAGGER).
+    const bool late = (IPDM_WINO2_STAGGER == 1 && swave >= 4) || IPDM_WINO2_STAGGER == 2;
     auto chunk = [&](auto first, int ch) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first)::value;
         const bool more1 = s + 1 < S;
         const int ch1 = ch + 1 == nchunks ? 0 : ch + 1, ch2 = ch1 + 1 == nchunks ? 0 : ch1 + 1;
-        if (more1) {
-            if (ch == nchunks - 1) { a_vm = g_vm; a_vmp = g_vmp; a_lsh = g_lsh; a_bord = g_bord; }      // chunk s + 1 opens the tile described last
-            activate();                                    // raw(s + 1) -> scratch
-        }
-        if (ch == nchunks - 2 && k + 1 < n_my) describe(k + 1);      // before the first loads of the next tile
-        issue_raw(ch2);                                    // raw(s + 2), consumed one iteration from now
+        auto stage_next = [&]() __attribute__((always_inline)) {
+            if (more1) {
+                if (ch == nchunks - 1) { a_vm = g_vm; a_vmp = g_vmp; a_lsh = g_lsh; a_bord = g_bord; }      // chunk s + 1 opens the tile described last
+                if (!(IPDM_WINO2_KO & 1)) activate();          // raw(s + 1) -> scratch
+            }
+            if (ch == nchunks - 2 && k + 1 < n_my) describe(k + 1);      // before the first loads of the next tile
+            if (!(IPDM_WINO2_KO & 8)) issue_raw(ch2);          // raw(s + 2), consumed one iteration from now
+        };
+        if (!late) stage_next();
         IPDM_STAMP(0)
         const float *stage = lds + (s & 1) * V_FLOATS;
 #pragma unroll
@@ -389,12 +402,21 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
             const float *vh = stage + kc * VH_FLOATS;
             f32x4 b_c = *reinterpret_cast<const f32x4 *>(vh + b_off), b_n;
             if (kc == 1) {
-                read_patch();                              // patch(s + 1) (behind the first operand: the LDS returns in order)
+                if (late) {
+                    stage_next();
+                    if (!(IPDM_WINO2_KO & 2)) { read_patch(); transform_patch((s + 1) & 1); }
+                } else if (!(IPDM_WINO2_KO & 2)) {
+                    read_patch();                          // patch(s + 1) (behind the first operand: the LDS returns in order)
+                }
                 if (ch1 == 0) w_co = g_co;                 // from here on the weights loaded belong to the tile described last
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                // the next position's operand BEFORE this position's MFMAs (pinned: left to itself the scheduler shares one
+                // register set between b_c and b_n, issues the read behind the MFMAs and waits for it at once -- an LDS
+                // latency per position)
                 if (e + 1 < 8) b_n = *reinterpret_cast<const f32x4 *>(vh + b_off + (e + 1) * 256);
+                __builtin_amdgcn_sched_barrier(0);
                 if (FIRST && kc == 0) {
                     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                     acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e][0], b_c[0], zero, 0, 0, 0);
@@ -404,12 +426,13 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
 #pragma unroll
                 for (int qq = 1; qq < 4; ++qq) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e][qq], b_c[qq], acc[e], 0, 0, 0);
                 // the U of this position for the NEXT sub-chunk, into the registers just read
-                issue_u(e, kc == 0 ? 2 * ch + 1 : 2 * ch1);
+                if (!(IPDM_WINO2_KO & 16)) issue_u(e, kc == 0 ? 2 * ch + 1 : 2 * ch1);
+                __builtin_amdgcn_sched_barrier(0);
                 if (e + 1 < 8) b_c = b_n;
             }
         }
         IPDM_STAMP(1)
-        transform_patch((s + 1) & 1);                      // V(s + 1); that stage was last read by chunk s - 1
+        if (!late && !(IPDM_WINO2_KO & 2)) transform_patch((s + 1) & 1);      // V(s + 1); that stage was last read by chunk s - 1
         IPDM_STAMP(2)
         __syncthreads();                                   // V(s + 1) complete; every wave is done with V(s)
         IPDM_STAMP(3)
@@ -419,6 +442,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         chunk(std::true_type{}, 0);
         for (int ch = 1; ch < nchunks; ++ch) chunk(std::false_type{}, ch);
         // ---------------------------------------------------------------- tile epilogue
+        if (IPDM_WINO2_KO & 4) { cur = TileId{g_n, g_oy, g_ox, g_co * BN}; continue; }
         // + bias through position (1, 1) (accumulator 5 of the ih = 0 waves), whose output coefficients are all 1
         if (ih == 0) {
             acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb, 1.0f, acc[5], 0, 0, 0);

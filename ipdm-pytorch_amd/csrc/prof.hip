@@ -48,13 +48,15 @@ extern "C" int ipdm_profile_begin(int32_t max_launches)
     return IPDM_OK;
 }
 
-// Stops recording; the caller must have synchronised the stream.  out_* are arrays of PROF_CLASSES
-// entries: total algorithmic FLOPs, total kernel milliseconds, launch count per class.
-extern "C" int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches)
+// Stops recording; the caller must have synchronised the stream.  out_* are arrays of n_classes entries (the caller
+// states its array length; the library has PROF_CLASSES classes and fails on a shorter array instead of overflowing it):
+// total algorithmic FLOPs, total kernel milliseconds, launch count per class.
+extern "C" int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches, int32_t n_classes)
 {
     IPDM_REQUIRE(out_flops && out_ms && out_launches, "profile_end: null argument");
+    IPDM_REQUIRE(n_classes >= PROF_CLASSES, "profile_end: arrays of %d entries, the library records %d classes", n_classes, PROF_CLASSES);
     g_prof.on = false;
-    for (int c = 0; c < PROF_CLASSES; ++c) { out_flops[c] = 0; out_ms[c] = 0; out_launches[c] = 0; }
+    for (int c = 0; c < n_classes; ++c) { out_flops[c] = 0; out_ms[c] = 0; out_launches[c] = 0; }
     for (size_t i = 0; i < g_prof.used; ++i) {
         const Rec &r = g_prof.pool[i];
         float ms = 0.f;

@@ -75,7 +75,8 @@ int conv_ws_k_chunk(int ks, int interleave);   // K chunk of the kernel a (ks, w
 // dominant kernel), 1 = every other conv variant, 2 = attention
 // 3 = the Winograd-domain form of class 0's layers, recorded with its EXECUTED flops (16/36 of the 3x3 count)
 // 4 = the narrow direct convolutions (conv_direct.hip), bandwidth-bound: recorded with their algorithmic HBM BYTES
-constexpr int PROF_CLASSES = 5;
+// 5 = the 128-cout-tile Winograd kernel (conv_wino2.hip; class 3 keeps the 64-cout-tile kernel), EXECUTED flops
+constexpr int PROF_CLASSES = 6;
 bool prof_enabled();
 void prof_before(int cls, hipStream_t st);
 void prof_after(int cls, double flops, hipStream_t st);

@@ -20,14 +20,21 @@ OPT_KEYS = ("timesteps_proj", "schedule_power_proj", "t_start_proj", "clip_proj"
             "fbp_sharpen", "ultra_img_denoise")
 
 
-def write_job(path, opt_dict, sino, draws, weight_seed, sharpen_num):
-    """draws: the recorded [1,1,h,w] tensors/arrays of ONE slice, in order (sinogram-shaped ones first, then image-shaped)."""
+SMOKE_PROJ = dict(in_channels=1, model_channels=16, out_channels=1, attention_resolutions=(16,), channel_mult=(0.25, 0.25, 0.5, 1, 2, 4), num_heads=1)
+SMOKE_IMG = dict(in_channels=1, model_channels=16, out_channels=1, attention_resolutions=(8,), channel_mult=(1, 1, 2, 2, 4), num_heads=1)
+
+
+def write_job(path, opt_dict, sino, draws, weight_seed, sharpen_num, dtype="float32", nets="full"):
+    """draws: the recorded [1,1,h,w] tensors/arrays of ONE slice, in order (sinogram-shaped ones first, then image-shaped).
+    dtype "float64": the ARBITER run -- the same float32 inputs, weights and draws evaluated in double precision.
+    nets "full": the production architectures, both with synthetic weights of seed `weight_seed`; "smoke": the reduced
+    16-channel networks of ipdm_pytorch_amd.denoiser.SMOKE_PROJ / SMOKE_IMG with weight seeds (weight_seed, weight_seed + 1)."""
     import numpy as np
     draws = [np.asarray(d, dtype=np.float32).reshape(d.shape[-2], d.shape[-1]) for d in draws]
     n_p = sum(1 for d in draws if d.shape == tuple(sino.shape))
     assert all(d.shape == tuple(sino.shape) for d in draws[:n_p]) and all(d.shape != tuple(sino.shape) for d in draws[n_p:])
     np.savez(path, sino=np.asarray(sino, dtype=np.float32), draws_p=np.stack(draws[:n_p]), draws_i=np.stack(draws[n_p:]),
-             opt=json.dumps({k: opt_dict[k] for k in OPT_KEYS}), weight_seed=weight_seed, sharpen_num=sharpen_num)
+             opt=json.dumps({k: opt_dict[k] for k in OPT_KEYS}), weight_seed=weight_seed, sharpen_num=sharpen_num, dtype=dtype, nets=nets)
 
 
 def cpu_blocks(njobs, threads):
@@ -71,12 +78,14 @@ def main():
     from oracle import pipeline as op, unet as ou
     j = np.load(job, allow_pickle=False)
     opt = json.loads(str(j["opt"]))
-    cfg_p, cfg_i = ou.UNetConfig(**FULL_PROJ), ou.UNetConfig(**FULL_IMG)
+    smoke = "nets" in j.files and str(j["nets"]) == "smoke"
+    dt = torch.float64 if ("dtype" in j.files and str(j["dtype"]) == "float64") else torch.float32
+    cfg_p, cfg_i = (ou.UNetConfig(**SMOKE_PROJ), ou.UNetConfig(**SMOKE_IMG)) if smoke else (ou.UNetConfig(**FULL_PROJ), ou.UNetConfig(**FULL_IMG))
     seed = int(j["weight_seed"])
-    sd_p = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_p), seed=seed).items()}
-    sd_i = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_i), seed=seed).items()}
-    draws = iter([torch.from_numpy(d)[None, None] for d in j["draws_p"]] + [torch.from_numpy(d)[None, None] for d in j["draws_i"]])
-    want, _ = op.progressive_slice(opt, cfg_p, sd_p, cfg_i, sd_i, torch.from_numpy(j["sino"])[None, None],
+    sd_p = {k: torch.from_numpy(v).to(dt) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_p), seed=seed).items()}
+    sd_i = {k: torch.from_numpy(v).to(dt) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_i), seed=seed + (1 if smoke else 0)).items()}
+    draws = iter([torch.from_numpy(d)[None, None].to(dt) for d in j["draws_p"]] + [torch.from_numpy(d)[None, None].to(dt) for d in j["draws_i"]])
+    want, _ = op.progressive_slice(opt, cfg_p, sd_p, cfg_i, sd_i, torch.from_numpy(j["sino"])[None, None].to(dt),
                                    lambda: next(draws), sharpen_num=int(j["sharpen_num"]))
     assert next(draws, None) is None, "the oracle consumed fewer draws than the device recorded"
     np.save(out, want.numpy())

@@ -1163,15 +1163,58 @@ def test_smoke_pipeline_fp64_arbiter():
         print("fp64 arbiter %-11s |hip-f64| max %.3e rms %.3e | |cpu32-f64| (16/32/64 threads) max %s rms %s | ratio max %.2f rms %.2f"
               % (name, h[0], h[1], ["%.2e" % x[0] for x in cs], ["%.2e" % x[1] for x in cs], h[0] / c[0], h[1] / c[1]))
         worst = max(worst, h[0] / c[0], h[1] / c[1])
-        # rms: 1.5x at every stage.  max-abs (one pixel out of 262k-1.8M): 1.5x up to the amplifying pass, 2x after it --
-        # there it is the extreme value of a chaotic amplification (the three oracle variants alone spread 2.5-3x in it)
+        # Up to the amplifying pass (both evaluations at 1e-7 of the arbiter) the comparison is sharp: 1.5x in rms and max-abs.
+        # After it one seed is one sample of a chaotic amplification (the three oracle variants alone spread 2.5-3x in
+        # max-abs): there the criterion is the MEDIAN over seeds of test_smoke_pipeline_fp64_arbiter_over_seeds
+        # (ARBITER_MEDIAN_*); this single sample only has to stay under the hard caps.
         amplified = c[1] > 1e-6
-        assert h[1] <= 1.5 * c[1] and h[0] <= (2.0 if amplified else 1.5) * c[0], (name, h, cs)
+        if amplified:
+            assert h[1] <= ARBITER_WORST_RMS * c[1] and h[0] <= ARBITER_WORST_MAX * c[0], (name, h, cs)
+        else:
+            assert h[1] <= 1.5 * c[1] and h[0] <= 1.5 * c[0], (name, h, cs)
     # float32 vs float32 at the end of the chain: bounded by what the arbiter justifies (the sum of the two distances)
     ff = dist(hip[2][-1], m32[1][2][-1])
     scale = float(np.abs(m64[2][-1]).max())
     print("fp64 arbiter: worst stage ratio %.2f; |hip-cpu32(32 threads)| at the end max %.3e rms %.3e (scale %.3f)" % (worst, ff[0], ff[1], scale))
     assert ff[0] <= E2E_MAX_REL * max(1.0, scale)
+
+
+def test_smoke_pipeline_fp64_arbiter_over_seeds(tmp_path):
+    """The fp64 arbiter as a statistic: the reduced end-to-end pipeline (proj loop 2+2 steps, FBP, sharpen, img loop, ultra
+    pass) for FIVE seeds -- network weights, phantom, dose noise and diffusion draws all vary -- each replayed by the CPU
+    oracle in float32 and in float64 (pinned child processes).  Median over the seeds of err(HIP, fp64) / err(oracle32,
+    fp64) at the END of the chain (after the amplifying image-domain passes): <= 1.25 in rms, <= 1.5 in max-abs."""
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG, _RecordingNoise
+    from ipdm_pytorch_amd.diffusion import NoiseSource
+    from ipdm_pytorch_amd.unet import UNetModel
+    from tests import _oracle_child as oc
+    hips, jobs32, jobs64 = [], [], []
+    for k, seed in enumerate((11, 29, 43, 61, 83)):
+        opt = default_cfg([])
+        cfg_load(mayo_test_options(), opt.__dict__)
+        cfg_load(dict(device=DEV, t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=True), opt.__dict__)
+        den = progressive_domain_denoiser(opt, seed=seed)
+        den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
+        den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
+        wseed = 100 + 2 * k
+        den.proj_model.load_state_dict({n: torch.from_numpy(v) for n, v in synth.synth_state_dict(den.proj_model._shapes, seed=wseed).items()})
+        den.img_model.load_state_dict({n: torch.from_numpy(v) for n, v in synth.synth_state_dict(den.img_model._shapes, seed=wseed + 1).items()})
+        sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(k + 1)), seed=k + 1)
+        den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
+        rec = _RecordingNoise(NoiseSource(seed, 0))
+        den.noise = rec
+        hips.append(den.progressive_denoiser(sharpen_num=70).cpu().numpy())
+        draws = [z.cpu().numpy() for z in rec.draws]
+        for dt, lst in (("float32", jobs32), ("float64", jobs64)):
+            job, out = str(tmp_path / ("smoke%d_%s.npz" % (seed, dt))), str(tmp_path / ("smoke%d_%s.npy" % (seed, dt)))
+            oc.write_job(job, opt.__dict__, sino, draws, wseed, 70, dtype=dt, nets="smoke")
+            lst.append((job, out))
+    outs = oc.run_jobs(jobs32 + jobs64, threads=12)
+    c32s, f64s = outs[:len(hips)], outs[len(hips):]
+    for h, c in zip(hips, c32s):
+        print("reduced pipeline: |hip - cpu32| max %.3e rms %.3e (scale %.3f)" % (np.abs(h - c).max(), np.sqrt(((h - c).astype(np.float64) ** 2).mean()), np.abs(c).max()))
+    _arbiter_ratios("reduced pipeline", hips, c32s, f64s)
 
 
 def test_pipeline_is_bit_reproducible():
@@ -1370,7 +1413,7 @@ def test_unet_true_size_vs_oracle(which):
     assert err <= 5e-5 * max(1.0, want.abs().max().item()), err
 
 
-def _full_size_run(opt_over, seed, phantoms, tmp_path, tag):
+def _full_size_run(opt_over, seed, phantoms, tmp_path, tag, arbiter=False):
     """The production networks at full size on the device (batch = len(phantoms), global slice ids 0..), the draws recorded,
     then every slice replayed by the CPU oracle in its own child process (tests/_oracle_child.py), side by side."""
     from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
@@ -1389,12 +1432,16 @@ def _full_size_run(opt_over, seed, phantoms, tmp_path, tag):
     draws = [z.cpu().numpy() for z in rec.draws]
     del den, rec
     torch.cuda.empty_cache()
-    jobs = []
+    jobs, jobs64 = [], []
     for b in range(len(phantoms)):
         job, out = str(tmp_path / ("%s_job%d.npz" % (tag, b))), str(tmp_path / ("%s_out%d.npy" % (tag, b)))
         oc.write_job(job, opt.__dict__, sinos[b], [d[b:b + 1] for d in draws], 0, 70)
         jobs.append((job, out))
-    return got, jobs
+        if arbiter:      # the same slice once more in float64: the value both float32 evaluations approximate
+            job, out = str(tmp_path / ("%s_job%d_f64.npz" % (tag, b))), str(tmp_path / ("%s_out%d_f64.npy" % (tag, b)))
+            oc.write_job(job, opt.__dict__, sinos[b], [d[b:b + 1] for d in draws], 0, 70, dtype="float64")
+            jobs64.append((job, out))
+    return (got, jobs, jobs64) if arbiter else (got, jobs)
 
 
 def _check_full_size(got, want, phantom, max_rel):
@@ -1415,18 +1462,54 @@ def _check_full_size(got, want, phantom, max_rel):
     return float(err.max()), rms, p_hip, p_cpu
 
 
+ARBITER_MEDIAN_RMS, ARBITER_MEDIAN_MAX = 1.25, 1.5       # median over the seeds of err(HIP, fp64) / err(oracle32, fp64)
+# Hard caps on the worst seed.  Measured (round 4, gpurun_out/arbiter_*.txt): full size -- the production kernels -- rms
+# ratios 0.98 ... 1.02, max-abs 0.93 ... 1.10 (nothing amplifies there: both evaluations end 1.3e-7 rms from the arbiter).  The
+# reduced random-weight networks amplify rounding chaotically: over five weight seeds the float32 ORACLE's own distance to the
+# arbiter spans 1.9e-7 ... 4.3e-4 rms, and the ratio of two such samples 0.86 ... 2.16 (rms), 0.75 ... 2.48 (max-abs) around
+# a median of 1.00 / 1.32 -- a single seed's ratio is noise, the median is the measurement.
+ARBITER_WORST_RMS, ARBITER_WORST_MAX = 4.0, 4.0
+
+
+def _arbiter_ratios(tag, hips, c32s, f64s):
+    """err(HIP, fp64) / err(CPU float32 oracle, fp64) per seed, rms and max-abs, asserted as a STATISTIC over the seeds:
+    a float32 evaluation of these chains ends a chaotic distance from the exact value (one seed's ratio says little), but
+    over seeds a library whose kernels round worse than the reference's would sit above 1 systematically."""
+    r_rms, r_max = [], []
+    for h, c, f in zip(hips, c32s, f64s):
+        eh, ec = np.abs(h.astype(np.float64) - f), np.abs(c.astype(np.float64) - f)
+        r_rms.append(float(np.sqrt((eh ** 2).mean()) / max(np.sqrt((ec ** 2).mean()), 1e-30)))
+        r_max.append(float(eh.max() / max(ec.max(), 1e-30)))
+        print("fp64 arbiter %s: |hip-f64| max %.3e rms %.3e | |cpu32-f64| max %.3e rms %.3e | ratio max %.2f rms %.2f"
+              % (tag, eh.max(), np.sqrt((eh ** 2).mean()), ec.max(), np.sqrt((ec ** 2).mean()), r_max[-1], r_rms[-1]))
+    msg = "fp64 arbiter %s over %d seeds: rms ratio median %.2f worst %.2f | max-abs ratio median %.2f worst %.2f" % (
+        tag, len(r_rms), float(np.median(r_rms)), max(r_rms), float(np.median(r_max)), max(r_max))
+    print(msg)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "arbiter_%s.txt" % tag.replace(" ", "_")), "w") as f:
+        f.write(msg + "\n" + "rms ratios %s\nmax-abs ratios %s\n" % (["%.3f" % x for x in r_rms], ["%.3f" % x for x in r_max]))
+    assert np.median(r_rms) <= ARBITER_MEDIAN_RMS and np.median(r_max) <= ARBITER_MEDIAN_MAX, msg
+    assert max(r_rms) <= ARBITER_WORST_RMS and max(r_max) <= ARBITER_WORST_MAX, msg
+
+
 def test_full_size_pipeline_psnr(tmp_path):
     """End to end at full size with the production architectures, few steps, FIVE seeds (weights fixed; phantom, dose
-    noise and diffusion draws vary): proj loop with adaptive guidance -> FBP -> sharpen -> img loop."""
+    noise and diffusion draws vary): proj loop with adaptive guidance -> FBP -> sharpen -> img loop -- against the float32
+    CPU oracle (north_star's PSNR criterion, max-abs 1e-4), and, with every slice replayed once more in FLOAT64, the fp64
+    arbiter on the PRODUCTION kernels (conv_wino2 / conv_wino / conv_ws / conv_direct / attention_ws / the parity form):
+    median over the seeds of err(HIP, fp64) / err(oracle32, fp64) <= 1.25 in rms and <= 1.5 in max-abs."""
     from tests import _oracle_child as oc
     runs = []
     for k, seed in enumerate((17, 23, 31, 47, 59)):
-        got, jobs = _full_size_run(dict(t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=False), seed, [4 + k], tmp_path,
-                                   "s%d" % seed)
-        runs.append((got, jobs[0], 4 + k))
-    wants = oc.run_jobs([j for _, j, _ in runs], threads=16)
-    report = [_check_full_size(got, want, ph, FULL_SIZE_MAX_REL) for (got, _, ph), want in zip(runs, wants)]
+        got, jobs, jobs64 = _full_size_run(dict(t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=False), seed, [4 + k], tmp_path,
+                                           "s%d" % seed, arbiter=True)
+        runs.append((got, jobs[0], jobs64[0], 4 + k))
+    outs = oc.run_jobs([j for _, j, _, _ in runs] + [j for _, _, j, _ in runs], threads=12)
+    wants, f64s = outs[:len(runs)], outs[len(runs):]
+    report = [_check_full_size(got, want, ph, FULL_SIZE_MAX_REL) for (got, _, _, ph), want in zip(runs, wants)]
     print("full-size 5 seeds: max-abs %s rms %s" % (["%.2e" % r[0] for r in report], ["%.2e" % r[1] for r in report]))
+    _arbiter_ratios("full size", [r[0] for r in runs], wants, f64s)
 
 
 def test_headline_configuration_full_length(tmp_path):

@@ -17,7 +17,11 @@ if os.environ.get("AB_NARROW"):      # the narrow layers of the projection UNet 
     CONVS = [(8, 8, 0, 2000, 912, 8, 3, 1, 2, 1), (8, 16, 0, 1000, 456, 16, 3, 1, 2, 1), (8, 16, 0, 2000, 912, 16, 3, 1, 0, 0),
              (8, 16, 8, 2000, 912, 8, 3, 1, 2, 0), (8, 144, 0, 1000, 456, 16, 3, 1, 2, 0), (8, 4, 0, 2000, 912, 8, 3, 1, 2, 0),
              (8, 16, 8, 2000, 912, 8, 1, 1, 0, 0), (8, 8, 0, 2000, 912, 1, 3, 1, 2, 0), (8, 1, 0, 2000, 912, 4, 3, 1, 0, 0)]
-ATTN = [(8, 4, 64, 7125), (8, 4, 64, 4096), (8, 4, 64, 1827), (8, 4, 64, 1024), (1, 4, 64, 4096)]
+if os.environ.get("AB_WINO"):        # the layers of the 128-cout Winograd kernel (conv_wino2)
+    CONVS = [(8, 128, 0, 512, 512, 128, 3, 1, 2, 1), (8, 128, 0, 512, 512, 128, 3, 1, 0, 0), (8, 256, 0, 128, 128, 256, 3, 1, 2, 1),
+             (8, 128, 0, 228, 500, 128, 3, 1, 2, 1), (8, 128, 128, 228, 500, 128, 3, 1, 2, 0), (8, 256, 0, 114, 250, 256, 3, 1, 2, 1),
+             (1, 128, 0, 512, 512, 128, 3, 1, 2, 1)]
+ATTN = [] if os.environ.get("AB_WINO") else [(8, 4, 64, 7125), (8, 4, 64, 4096), (8, 4, 64, 1827), (8, 4, 64, 1024), (1, 4, 64, 4096)]
 for l in libs:
     l.ipdm_bench_attention.argtypes = [C.c_int32] * 5 + [C.POINTER(C.c_float)]
 ms = C.c_float()

@@ -34,19 +34,20 @@ def per_kernel(db, counter):
 def main(fetch_db, write_db, tag):
     f, dur = per_kernel(fetch_db, "FETCH_SIZE")
     w, _ = per_kernel(write_db, "WRITE_SIZE")
-    dom = [k for k in f if "conv_wino_kernel" in k]
+    dom = [k for k in f if "conv_wino2_kernel" in k] or [k for k in f if "conv_wino_kernel" in k]
     if not dom or os.environ.get("IPDM_CONV_NO_WINO"):
         dom = [k for k in f if "conv_ws_kernel<3, 1," in k]
     nl = sum(f[k][1] for k in dom)
     fetch = sum(f[k][0] * f[k][1] for k in dom) / nl
     write = sum(w[k][0] * w[k][1] for k in dom if k in w) / nl
-    src = "conv_wino.hip" if any("conv_wino_kernel" in k for k in dom) else "conv_ws.hip"
+    src = "conv_wino2.hip" if any("conv_wino2_kernel" in k for k in dom) else ("conv_wino.hip" if any("conv_wino_kernel" in k for k in dom) else "conv_ws.hip")
     with open(os.path.join(ROOT, "ipdm-pytorch_amd", "csrc", src), "rb") as fh:
         sha = hashlib.sha256(fh.read()).hexdigest()[:16]
     mode = {"3": "split-bf16-x6", "2": "split-bf16-x3"}.get(os.environ.get("IPDM_CONV_SPLIT", ""), "exact-f32")
     if os.environ.get("IPDM_CONV_NO_WINO"):
         mode += "-nowino"
-    d = {"tag": tag, "kernel": "conv_wino_kernel (wide 3x3 stride-1, Winograd domain)" if src == "conv_wino.hip" else "conv_ws_kernel<3,1,*> (3x3 stride-1)",
+    d = {"tag": tag, "kernel": {"conv_wino2.hip": "conv_wino2_kernel (wide 3x3 stride-1, Winograd domain, 128-cout tiles)",
+                                "conv_wino.hip": "conv_wino_kernel (wide 3x3 stride-1, Winograd domain, 64-cout tiles)"}.get(src, "conv_ws_kernel<3,1,*> (3x3 stride-1)"),
          "mode": mode, "kernel_source_sha16": sha,
          "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python3 bench.py --steps 1 --warmup 0 "
                    "--t_start_proj 3 --t_start_img 2 --no-ultra (B=8: the headline's 3:2 mix of proj and img UNet forwards)",
