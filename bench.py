@@ -226,11 +226,18 @@ def main():
         return den._img_dense(x, None, False)[-1]
     ldct = ldct_images() if img_only else None
 
+    own_done = [0.0]
+
     def step():
         if img_only:
             out = img_only_step(ldct)
         else:
             out = den.proj_denoiser_device()[0] if alt else den.progressive_denoiser_device(sharpen_num=70)
+        if world > 1:
+            # this rank's own finish time, BEFORE the all-gather makes everybody wait for the slowest rank (reported per
+            # rank beside the max: a scaling record then shows imbalance, not just its effect)
+            torch.cuda.synchronize()
+            own_done[0] = time.perf_counter()
         return idist.all_gather_slices(out, n_global, rank, world)
 
     for _ in range(args.warmup):
@@ -250,6 +257,8 @@ def main():
     idist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # per rank: the time at which its own slices of the LAST step were finished (steps before it end in the all-gather)
+    own_ms = idist.gather_over_ranks(((own_done[0] - t0) if world > 1 else elapsed) / args.steps * 1e3, device)
     elapsed = idist.max_over_ranks(elapsed, device)
     roofline = None
     extra = {}
@@ -306,6 +315,9 @@ def main():
                                        n_fwd_proj, n_fwd_img, args.t_start_proj, args.t_start_img, not args.no_ultra),
                        "slices_per_gpu": B, "global_batch": n_global, "parallelism": "slice-sharded x%d" % world,
                        "rccl_ranks": idist.describe(),
+                       "per_rank_ms_per_step": {"min": round(min(own_ms), 2), "max": round(max(own_ms), 2),
+                                                "all": [round(v, 2) for v in own_ms],
+                                                "note": "each rank's own slices finished (before the all-gather)"},
                        "weights": "random-init reference architectures (29.1M img / 28.4M proj params)",
                        "work_per_slice": "85.1 TFLOP as the reference evaluates it.  Executed here: the Upsample layers (nearest 2x + "
                                          "3x3 conv) as four 2x2-tap parity convolutions over pre-added weights (4 of 9 multiply-adds per "
@@ -347,6 +359,21 @@ def main():
                 "note": "one slice alone through the same pipeline (warm-up + 1 timed pass), launches issued one by one / UNet "
                         "forwards replayed from hipGraphs; the gap to B=8 is chip under-fill of the low-resolution layers "
                         "(DESIGN 6e)"}
+            # ---- the DROP-IN call: the reference-shaped progressive_denoiser() (Utils/train_test_utils.py:552-567) on the
+            # same B slices -- result dictionaries on the host, the FBP image through the host, as a caller of the
+            # reference's surface gets it; the headline times the device-resident form of the same arithmetic
+            den.data_sample_load(ldproj=ldproj)
+
+            def drop_in():
+                den._noise().draw = draw0
+                return den.progressive_denoiser(sharpen_num=70)
+            dtd, od_ = timed_leg(drop_in)
+            od_ = od_ if torch.is_tensor(od_) else torch.as_tensor(od_)
+            line["config"]["drop_in"] = {
+                "ms_per_step": round(dtd * 1e3, 2), "slices_per_s": round(B / dtd, 5), "ratio_to_device_form": round(dtd / (elapsed / args.steps), 4),
+                "equals_device_form": bool(torch.equal(od_.to(out.device).reshape(out.shape), out)),
+                "note": "progressive_domain_denoiser.progressive_denoiser(): the reference's call (host-side result dictionaries, D2H "
+                        "/ H2D of the converted image) on the headline's batch and draws; `value` is the device-resident form"}
             # ---- BASELINE config C3 at its literal shape: B x [1152 views x 736 detectors], proj UNet x45 + HIP FBP
             den.set_fbp_geometry(**ALT_GEOMETRY)
             den.data_sample_load(ldproj=make_inputs(B, lo, device, ALT_GEOMETRY))

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 #include "../../include/ipdm_hip.h"
 
 namespace ipdm {
@@ -59,6 +60,8 @@ const char *opt_name(int o);
 void opt_snapshot(int (&dst)[OPT_COUNT]);
 // first entry (not per-call) whose current value differs from `rec`, or -1
 int opt_changed_since(const int (&rec)[OPT_COUNT]);
+// the current values of the per-call entries, in table order (graph keys)
+std::vector<int> opt_per_call_values();
 
 // hipFuncAttributeMaxDynamicSharedMemorySize for kernels that use more than 64 KiB of LDS: set once per
 // (kernel, device), under a lock -- handles may be driven from different threads and devices of one process.

@@ -24,18 +24,28 @@ int g_cus[64];                                         // per device ordinal, 0 
 
 // ---------------------------------------------------------------------------------------------- options
 namespace {
-struct OptDef { const char *name; int def; bool per_call; };
+struct OptDef { const char *name; int def; bool per_call; int lo = 0, hi = 1; };      // [lo, hi]: what ipdm_set_option accepts
 const OptDef g_opt_def[OPT_COUNT] = {
-    {"conv_split", 0, false}, {"attn_split", 0, false}, {"conv_no_up2", 0, true},
+    {"conv_split", 0, false, 0, 3}, {"attn_split", 0, false, 0, 3}, {"conv_no_up2", 0, true},
     {"conv_legacy", 0, false}, {"conv1x1_legacy", 0, false}, {"convs2_legacy", 0, false},
-    {"conv_no_direct", 0, false}, {"direct_no_planar", 0, false}, {"direct_max_cin", 160, false}, {"direct_no_s2", 0, false}, {"direct_no_skip_fuse", 0, true},
-    {"conv_sx_cw2", 0, false}, {"conv_dbg", 0, true}, {"conv_vec4_strict", 0, false}, {"conv_no_splitk", 0, false},
-    {"conv_no_wino", 0, true}, {"wino_v1", 0, true}, {"wino2_min_tiles", 192, true}, {"wino_split_min_tiles", 0, true}, {"conv1x1_no_quarter", 0, true}, {"conv_nm", 0, true},
+    {"conv_no_direct", 0, false}, {"direct_no_planar", 0, false},
+    {"direct_max_cin", 160, false, 0, 160},      // (conv_direct's LDS staging and chunk loop are sized for at most 160 input channels)
+    {"direct_no_s2", 0, false}, {"direct_no_skip_fuse", 0, true},
+    {"conv_sx_cw2", 0, false}, {"conv_dbg", 0, true, 0, 0x3ff}, {"conv_vec4_strict", 0, false}, {"conv_no_splitk", 0, false},
+    {"conv_no_wino", 0, true}, {"wino_v1", 0, true}, {"wino2_min_tiles", 192, true, 0, 1 << 24}, {"wino_split_min_tiles", 0, true, 0, 1 << 24},
+    {"conv1x1_no_quarter", 0, true}, {"conv_nm", 0, true, 0, 2},
     {"gn_two_stage", 0, true}, {"gn_unfused", 0, true},
-    {"unet_transpose", -1, true},
+    {"unet_transpose", -1, true, -1, 1},
     {"attn_no_kvsplit", 0, false}, {"attn_legacy", 0, false}, {"attn_no_zseq", 0, true},
     {"art_per_view", 0, true},
 };
+bool opt_value_ok(int i, int v)
+{
+    if (v < g_opt_def[i].lo || v > g_opt_def[i].hi) return false;
+    if (i == OPT_CONV_SPLIT) return v == 0 || v == 2 || v == 3;
+    if (i == OPT_ATTN_SPLIT) return v == 0 || v == 3;
+    return true;
+}
 std::mutex g_opt_mu;
 int g_opt_val[OPT_COUNT];
 bool g_opt_init = false;
@@ -53,7 +63,9 @@ void opt_init_locked()
         if (e) {                       // presence switches a flag on; a number is taken as the value ("0" switches it off)
             char *end = nullptr;
             const long v = strtol(e, &end, 10);
-            g_opt_val[i] = (end != e) ? (int)v : 1;
+            const int want = (end != e) ? (int)v : 1;
+            if (opt_value_ok(i, want)) g_opt_val[i] = want;
+            else fprintf(stderr, "libipdm_hip: %s=%s is outside the option's range [%d, %d]: ignored\n", env, e, g_opt_def[i].lo, g_opt_def[i].hi);
         }
     }
     g_opt_init = true;
@@ -73,6 +85,15 @@ void opt_snapshot(int (&dst)[OPT_COUNT])
     std::lock_guard<std::mutex> lk(g_opt_mu);
     opt_init_locked();
     for (int i = 0; i < OPT_COUNT; ++i) dst[i] = g_opt_val[i];
+}
+std::vector<int> opt_per_call_values()
+{
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    opt_init_locked();
+    std::vector<int> v;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (g_opt_def[i].per_call) v.push_back(g_opt_val[i]);
+    return v;
 }
 int opt_changed_since(const int (&rec)[OPT_COUNT])
 {
@@ -120,6 +141,8 @@ extern "C" int ipdm_set_option(const char *name, int value)
 {
     const int i = ipdm::opt_find(name);
     IPDM_REQUIRE(i >= 0, "ipdm_set_option: unknown option '%s'", name ? name : "(null)");
+    IPDM_REQUIRE(ipdm::opt_value_ok(i, value), "ipdm_set_option: %s = %d is outside [%d, %d]%s", ipdm::g_opt_def[i].name, value,
+                 ipdm::g_opt_def[i].lo, ipdm::g_opt_def[i].hi, (i == ipdm::OPT_CONV_SPLIT || i == ipdm::OPT_ATTN_SPLIT) ? " (or not one of its modes)" : "");
     std::lock_guard<std::mutex> lk(ipdm::g_opt_mu);
     ipdm::opt_init_locked();
     ipdm::g_opt_val[i] = value;

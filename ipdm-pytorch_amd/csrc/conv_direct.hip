@@ -463,6 +463,11 @@ int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29),
                  "conv2d: per-sample tensor exceeds the 2 GiB buffer-addressing range");
     IPDM_REQUIRE(!a.sk_w || conv_direct_skip_ok(a), "conv2d: this layer cannot carry a fused shortcut");
+    // (with a fused shortcut the block INPUT -- up to direct_max_cin channels -- is the larger source: its descriptors are built
+    //  in 32-bit arithmetic like the main input's)
+    IPDM_REQUIRE(!a.sk_w || ((long)a.sk_C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.sk_C2 + 1) * a.Hs * a.Ws < (1L << 29)),
+                 "conv2d: the fused shortcut's source exceeds the 2 GiB buffer-addressing range");
+    IPDM_REQUIRE(!a.sk_w || !a.sk_planar || (!(a.Hs & 1) && !(a.Ws & 1)), "conv2d: parity-planar shortcut source of odd size %dx%d", a.Hs, a.Ws);
     if (!a.sk_w && conv_nm_eligible(a)) return conv2d_nm_launch(a, st);      // same tiles, same statistics rows: interchangeable
     if (a.stride == 2) {
         if (a.Cout <= 4) return launch_direct_s2<4>(a, st);

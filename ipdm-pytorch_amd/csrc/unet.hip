@@ -391,7 +391,8 @@ struct ipdm_unet {
     std::vector<Tensor *> live;
     // captured forwards (ipdm_unet_forward_graph): one executable graph per (t, batch, size, buffers)
     struct GraphKey {
-        int t, B, H, W; const void *x, *eps, *ws; int mode;
+        int t, B, H, W; const void *x, *eps, *ws;
+        std::vector<int> mode;                  // the values of EVERY per-call option at capture time (opt_per_call_values)
         bool operator<(const GraphKey &o) const
         {
             return std::tie(t, B, H, W, x, eps, ws, mode) < std::tie(o.t, o.B, o.H, o.W, o.x, o.eps, o.ws, o.mode);
@@ -895,10 +896,12 @@ int run_forward(ipdm_unet *net, const float *d_x, int t, float *d_eps, int B, in
     net->gn_shift = (float *)w; w += align_up(((size_t)B * net->max_ch + 64) * sizeof(float), 256);
     net->gn_part = (double *)w;
     if (!dry) {
-        // the convolutions' prologue reads a K chunk past [B, C] without selects (channels beyond Cin carry zero weights,
-        // but NaN * 0 is NaN): the read-ahead floats are zeroed, once per forward
-        (void)hipMemsetAsync(net->gn_scale + (size_t)B * net->max_ch, 0, 64 * sizeof(float), st);
-        (void)hipMemsetAsync(net->gn_shift + (size_t)B * net->max_ch, 0, 64 * sizeof(float), st);
+        // the convolutions' prologue reads a K chunk past [B, Ctot] without selects (channels beyond Cin carry zero weights,
+        // but NaN * 0 is NaN).  For a layer with Ctot < max_ch that read-ahead lands INSIDE the arrays, at [B * Ctot,
+        // B * Ctot + chunk), which no finalize of that layer writes: both arrays are zeroed whole, once per forward
+        // ((B * max_ch + 64) floats each: a few KB)
+        (void)hipMemsetAsync(net->gn_scale, 0, ((size_t)B * net->max_ch + 64) * sizeof(float), st);
+        (void)hipMemsetAsync(net->gn_shift, 0, ((size_t)B * net->max_ch + 64) * sizeof(float), st);
     }
     net->ws = (char *)d_ws + fixed;
     net->arena.reset(dry ? (size_t)1 << 46 : ws_bytes - fixed);
@@ -1006,11 +1009,9 @@ extern "C" int ipdm_unet_forward_graph(ipdm_unet *net, const float *d_x, int32_t
         set_error("unet_forward_graph: option '%s' changed after ipdm_unet_create", opt_name(ch));
         return IPDM_ERR_INVALID;
     }
-    // every per-call switch that changes the recorded launches is part of the key
-    const int mode = (opt(OPT_GN_UNFUSED) ? 1 : 0) | ((opt(OPT_UNET_TRANSPOSE) + 1) << 1) | (opt(OPT_CONV_NO_UP2) ? 8 : 0) |
-                     (opt(OPT_GN_TWO_STAGE) ? 16 : 0) | (opt(OPT_ATTN_NO_ZSEQ) ? 32 : 0) | (opt(OPT_CONV_NO_WINO) ? 64 : 0) |
-                     (opt(OPT_CONV1X1_NO_QUARTER) ? 128 : 0) | ((opt(OPT_CONV_NM) & 3) << 8) | (opt(OPT_DIRECT_NO_SKIP_FUSE) ? 1024 : 0) |
-                     (opt(OPT_WINO_SPLIT_MIN_TILES) << 11);
+    // every per-call switch may change the recorded launches: the whole vector of their values is part of the key (a packed
+    // bit field aliased values that did not fit their bits, and missed switches added later)
+    const std::vector<int> mode = opt_per_call_values();
     const ipdm_unet::GraphKey key{t, B, H, W, d_x, d_eps, d_ws, mode};
     auto it = net->graphs.find(key);
     if (it != net->graphs.end()) {

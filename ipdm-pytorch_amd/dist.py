@@ -82,3 +82,16 @@ def max_over_ranks(value, device):
     t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value, device):
+    """Every rank's scalar, in rank order (identical on all ranks): bench.py reports the per-rank step times beside their
+    maximum, so that a scaling record shows load imbalance and not just its effect."""
+    if not dist.is_initialized():
+        return [float(value)]
+    world = dist.get_world_size()
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    mine = torch.tensor([value], dtype=torch.float64, device=dev)
+    out = torch.empty(world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, mine)
+    return [float(v) for v in out.cpu()]

@@ -85,3 +85,18 @@ def test_options_table_without_a_gpu():
     import pytest
     with pytest.raises(_lib.IpdmError, match="unknown option"):
         _lib.set_option("no_such_switch", 1)
+
+
+def test_option_values_are_range_checked():
+    """ipdm_set_option refuses values outside an option's range (status code + message, the old value stays): a packed
+    graph key or a kernel's static limits must never see them."""
+    from ipdm_pytorch_amd import _lib
+    lib = _lib.lib()
+    for name, bad in (("conv_nm", 4), ("wino_split_min_tiles", -1), ("unet_transpose", 2), ("direct_max_cin", 4096), ("conv_split", 1),
+                      ("conv_no_wino", 7)):
+        old = _lib.get_option(name)
+        rc = lib.ipdm_set_option(name.encode(), bad)
+        assert rc != 0 and name.encode() in lib.ipdm_last_error(), (name, rc, lib.ipdm_last_error())
+        assert _lib.get_option(name) == old
+    with _lib.option("unet_transpose", 1), _lib.option("conv_split", 3):
+        assert _lib.get_option("unet_transpose") == 1 and _lib.get_option("conv_split") == 3

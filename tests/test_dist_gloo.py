@@ -1,4 +1,4 @@
-"""world_size-2 `gloo` tests of the N>1 path on CPU: contiguous slice sharding, the single end-of-path
+"""world_size-2 and world_size-8 `gloo` tests of the N>1 path on CPU: contiguous slice sharding, the single end-of-path
 all-gather (equal and ragged shards), max-over-ranks timing, and that sharded per-slice work is
 identical to the unsharded result (the reference has no multi-device path)."""
 import os
@@ -93,11 +93,14 @@ def _worker(rank, world, port, n_slices, q):
     out = idist.all_gather_slices(local, n_slices, r, w)
     want = _per_slice_work(full, 0)
     t = idist.max_over_ranks(1.0 + rank, "cpu")
+    per_rank = idist.gather_over_ranks(10.0 + rank, "cpu")          # what bench.py prints beside the max: every rank's step time
+    assert per_rank == [10.0 + r for r in range(world)], per_rank
     # adaptive pass schedule (t_start_proj=None): every rank must take the branch of the GLOBAL Delta-map maximum
     import types
     from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser
     hook = progressive_domain_denoiser._rank_max(types.SimpleNamespace(proj_device="cpu"))
     assert hook is not None and hook(3.0 if rank == 0 else 40.0) == 40.0
+    assert hook(float((rank * 5) % world)) == float(max((r * 5) % world for r in range(world)))      # the maximum sits on a middle rank
     idist.barrier()
     q.put((rank, bool(torch.equal(out, want)), tuple(out.shape), t, (lo, hi)))
     torch.distributed.destroy_process_group()
@@ -122,6 +125,31 @@ def test_shard_and_all_gather_world2(n_slices):
         assert t == 2.0                       # max over ranks of (1.0, 2.0)
         ranges.append(rng)
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == n_slices
+
+
+def test_shard_and_all_gather_world8_ragged_batch():
+    """EIGHT ranks (the node the headline scales to: BASELINE config C5) over a ragged global batch of 61 slices -- five
+    ranks with 8, three with 7: contiguous shards, the padded all-gather, per-rank timings, the MAX all-reduce of the timing
+    and of the adaptive t_start=None branch (every rank takes the branch of the global Delta-map maximum)."""
+    n_slices, world = 61, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_slices, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world))
+    for rank, same, shape, t, rng in res:
+        assert same, "rank %d: gathered result differs from the unsharded one" % rank
+        assert shape == (n_slices, 1, 2, 3) and t == float(world)
+    sizes = [hi - lo for _, _, _, _, (lo, hi) in res]
+    assert sizes == [8] * 5 + [7] * 3 and res[0][4][0] == 0 and res[-1][4][1] == n_slices
+    for a, b in zip(res, res[1:]):
+        assert a[4][1] == b[4][0]
 
 
 def test_shard_range_partitions():

@@ -665,6 +665,22 @@ def test_wino128_fused_statistics_and_planar_reader():
                 test_upsample_conv_parity_form(case)
 
 
+def test_direct_fallback_of_the_winograd_layers():
+    """conv_no_wino (per call; bench.py's '-nowino' mode): the layers the Winograd kernels take by default on the direct
+    implicit-GEMM kernel (conv_ws) -- plain, concat, fused-statistics producer, parity-planar reader -- so that the shipped
+    fallback stays covered now that every wide op-level case uploads Winograd weights."""
+    from ipdm_pytorch_amd import _lib
+    with _lib.option("conv_no_wino", 1):
+        assert _lib.lib().ipdm_conv_kernel_code(8, 128, 128, 3, 1, 64, 96) == 3
+        for i, case in enumerate([(8, 128, 0, 64, 96, 64, 96, 128, 3, 1, 2, True), (2, 64, 64, 48, 40, 48, 40, 64, 3, 1, 2, True),
+                                  (2, 128, 0, 19, 250, 19, 250, 128, 3, 1, 2, True), (2, 128, 64, 203, 90, 203, 90, 256, 3, 1, 2, False)]):
+            _conv_case(*case, seed=7300 + i)
+        _conv_gn_conv((4, 128, 200, 96, 128, 3, 1, True, 2, 64))
+        _conv_gn_conv((2, 128, 26, 250, 128, 3, 1, True, 2, 64))
+        test_upsample_conv_parity_form((1, 128, 40, 72, 128, 64, 128, 3, 2))
+        test_upsample_conv_parity_form((2, 64, 33, 47, 64, 0, 64, 3, 2))
+
+
 def test_k_split_layers_on_the_winograd_kernel_opt_in():
     """Option wino_split_min_tiles (off by default: DESIGN 8): layers the direct tiling splits along K take the Winograd
     kernel instead -- same tolerance, same fused statistics rows as every other producer."""
@@ -872,6 +888,28 @@ def _native_unet(kw, seed):
     sd = synth.synth_state_dict(net._shapes, seed=seed)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return net, {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def test_unet_channel_counts_off_the_chunk_size_with_a_poisoned_workspace():
+    """model_channels = 20 with channel_mult (1, 2, 4): wide 3x3 layers whose input channel counts (60, 100, 120 after the
+    concats) are NOT multiples of the 8-channel K chunk, so their prologue reads GroupNorm scale / shift entries past
+    [B, Cin] -- inside the arrays, where no layer's finalize writes.  The workspace is filled with NaN bit patterns before
+    the forward: the result must still match the CPU oracle (the executor zeroes both arrays once per forward), and the
+    Winograd switch must not matter (conv_no_wino: the direct kernel stays the covered fallback of those layers)."""
+    from ipdm_pytorch_amd import _lib
+    kw = dict(in_channels=1, model_channels=20, out_channels=1, attention_resolutions=(), channel_mult=(1, 2, 4), num_heads=1)
+    net, sd = _native_unet(kw, 17)
+    x = torch.from_numpy(synth.hash_normal((2, 1, 40, 72), 911))
+    want = ou.unet_forward(ou.UNetConfig(**kw), sd, x, 5)
+    outs = []
+    for no_wino in (0, 1):
+        with _lib.option("conv_no_wino", no_wino):
+            net.workspace(2, 40, 72).fill_(0xFF)                 # every float of the arena a NaN
+            got = net(x.to(DEV), 5).cpu()
+        assert bool(torch.isfinite(got).all())
+        assert (got - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max())), float((got - want).abs().max())
+        outs.append(got)
+    assert (outs[0] - outs[1]).abs().max() <= 1e-5
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "d"])
