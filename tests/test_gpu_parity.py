@@ -891,13 +891,13 @@ def _native_unet(kw, seed):
 
 
 def test_unet_channel_counts_off_the_chunk_size_with_a_poisoned_workspace():
-    """model_channels = 20 with channel_mult (1, 2, 4): wide 3x3 layers whose input channel counts (60, 100, 120 after the
-    concats) are NOT multiples of the 8-channel K chunk, so their prologue reads GroupNorm scale / shift entries past
+    """Levels of 20, 60 and 64 channels: wide 3x3 layers whose input channel counts (20, 60, 124 = 64 + 60 after a concat)
+    are NOT multiples of the 8-channel K chunk, so their prologue reads GroupNorm scale / shift entries past
     [B, Cin] -- inside the arrays, where no layer's finalize writes.  The workspace is filled with NaN bit patterns before
     the forward: the result must still match the CPU oracle (the executor zeroes both arrays once per forward), and the
     Winograd switch must not matter (conv_no_wino: the direct kernel stays the covered fallback of those layers)."""
     from ipdm_pytorch_amd import _lib
-    kw = dict(in_channels=1, model_channels=20, out_channels=1, attention_resolutions=(), channel_mult=(1, 2, 4), num_heads=1)
+    kw = dict(in_channels=1, model_channels=64, out_channels=1, attention_resolutions=(), channel_mult=(0.3125, 0.9375, 1), num_heads=1)
     net, sd = _native_unet(kw, 17)
     x = torch.from_numpy(synth.hash_normal((2, 1, 40, 72), 911))
     want = ou.unet_forward(ou.UNetConfig(**kw), sd, x, 5)
