@@ -281,6 +281,7 @@ int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
  *   3 = conv_ws (direct implicit GEMM, f32 MFMA)            4 = conv_ws with a K split + combine pass
  *   5 = conv_direct (narrow layers, packed-f32 VALU)        6 = conv_nm (opt-in 16-cout MFMA)
  *   7 = parity form of an Upsample (never for this plain shape)   8 = conv_igemm (the generic 4-wave kernel)
+ *   9 = conv_wino2 with K slices + combine pass (the layers with too few tiles per sample)
  *   102 | 103 = opt-in split-bf16;  -1 = bad argument.
  * Test aid (replaces nothing in the reference): a parity test asserts the kernel it believes it covers. */
 int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W);

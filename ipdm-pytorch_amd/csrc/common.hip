@@ -32,7 +32,7 @@ const OptDef g_opt_def[OPT_COUNT] = {
     {"direct_max_cin", 160, false, 0, 160},      // (conv_direct's LDS staging and chunk loop are sized for at most 160 input channels)
     {"direct_no_s2", 0, false}, {"direct_no_skip_fuse", 0, true},
     {"conv_sx_cw2", 0, false}, {"conv_dbg", 0, true, 0, 0x3ff}, {"conv_vec4_strict", 0, false}, {"conv_no_splitk", 0, false},
-    {"conv_no_wino", 0, true}, {"wino_v1", 0, true}, {"wino2_min_tiles", 192, true, 0, 1 << 24}, {"wino_split_min_tiles", 0, true, 0, 1 << 24},
+    {"conv_no_wino", 0, true}, {"wino_v1", 0, true}, {"wino2_min_tiles", 192, true, 0, 1 << 24},
     {"conv1x1_no_quarter", 0, true}, {"conv_nm", 0, true, 0, 2},
     {"gn_two_stage", 0, true}, {"gn_unfused", 0, true},
     {"unet_transpose", -1, true, -1, 1},

@@ -389,7 +389,10 @@ int conv_kernel_code(const ConvArgs &a)
     if (conv_sx_pieces(a.w_interleave)) return 100 + conv_sx_pieces(a.w_interleave);
     if (a.w_interleave) {
         if (conv_up2_eligible(a)) return 7;
-        if (conv_wino_eligible(a)) return (!opt(OPT_WINO_V1) && conv_wino2_eligible(a)) ? 2 : 1;
+        if (conv_wino_eligible(a)) {
+            if (a.split_ws && conv_split(a) > 1) return 9;
+            return (!opt(OPT_WINO_V1) && conv_wino2_eligible(a)) ? 2 : 1;
+        }
         return (a.split_ws && conv_ws_split(a) > 1) ? 4 : 3;
     }
     if (!opt(OPT_CONV_NO_DIRECT) && conv_direct_eligible(a)) return conv_nm_eligible(a) ? 6 : 5;
@@ -407,7 +410,8 @@ int conv_stats_rows(const ConvArgs &a)
 
 int conv_split(const ConvArgs &a)
 {
-    if (conv_sx_pieces(a.w_interleave) || !a.w_interleave || conv_wino_eligible(a)) return 1;
+    if (conv_sx_pieces(a.w_interleave) || !a.w_interleave) return 1;
+    if (conv_wino_eligible(a)) return conv_ws_split(a) > 1 ? conv_wino_split(a) : 1;      // (K slices inside conv_wino2)
     return conv_ws_split(a);
 }
 size_t conv_split_ws_bytes(const ConvArgs &a)

@@ -713,8 +713,9 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
 namespace ipdm {
 
 // Which convolutions run in the Winograd domain: wide 3x3 stride-1 layers with packed U weights, whole 64-cout tiles and
-// whole 8-channel chunks, no resampling on the way in, not a K-split layer (those have too few tiles for any tiling).  The
-// rule looks at the layer only, never at the batch size.
+// whole 8-channel chunks, no resampling on the way in.  Layers the direct tiling splits along K (conv_ws_split(a) > 1: too few
+// tiles for any tiling) run here too when the 128-cout kernel can split them itself (conv_wino_split: K slices INSIDE
+// conv_wino2, round 4), otherwise they stay on the K-split direct kernel.  The rule looks at the layer only, never at the batch.
 bool conv_wino_eligible(const ConvArgs &a)
 {
     if (opt(OPT_CONV_NO_WINO) || !a.w_wino) return false;
@@ -724,14 +725,7 @@ bool conv_wino_eligible(const ConvArgs &a)
     if (a.Cout % BN || Ctot % KC || Ctot < 32 || (a.C2 && a.C1 % KC)) return false;
     if ((a.x1_planar && ((a.Hs | a.Ws) & 1)) || conv_up2_eligible(a)) return false;
     if (conv_ws_split(a) == 1) return true;
-    // Layers the direct tiling splits along K (<= 16 tiles of 8x32x128 per sample): this tiling has 4-8x more tiles (4x32
-    // pixels x 64 couts), enough to fill the chip at the benched batch without a split.  OPT-IN (wino_split_min_tiles = N > 0:
-    // taken from N tiles per sample; a rule of the layer alone): measured with N = 64 on 256->256 @63x29, 1.59x faster at B = 8
-    // (0.125 vs 0.199 ms: +1.2 % on the benched step) and 1.4-1.6x SLOWER for a lone slice (64 workgroups with one
-    // 32-chunk tile each: 0.057 vs 0.041 ms, +1.8 % on the B = 1 latency) -- the default keeps the lone slice.
-    const int min_tiles = opt(OPT_WINO_SPLIT_MIN_TILES);
-    const long wt = (long)cdiv(a.Ho, TH) * cdiv(a.Wo, TW) * (a.Cout / BN);
-    return min_tiles > 0 && wt >= min_tiles;
+    return !opt(OPT_WINO_V1) && conv_wino_split(a) > 1;
 }
 
 bool conv_wino_shape_ok(int Cout, int Cin, int ks, int stride, int interleave)
@@ -768,7 +762,7 @@ int conv2d_wino_launch(const ConvArgs &args, hipStream_t st)
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = cdiv(a.Ho, TH);
     a.co_tiles = a.Cout / BN;
-    a.ksplit = 1;
+    a.ksplit = args.ksplit > 1 ? args.ksplit : 1;
     a.dbg = (a.dbg_buf ? (opt(OPT_CONV_DBG) & 56) : 0) | (opt(OPT_CONV_DBG) & 7);
     IPDM_REQUIRE(conv_wino_eligible(args), "conv2d_wino: layer not eligible");
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29) &&
@@ -782,7 +776,8 @@ int conv2d_wino_launch(const ConvArgs &args, hipStream_t st)
     G = (G + 7) / 8 * 8;
     const void *fn = a.x1_planar ? (const void *)conv_wino_kernel<true> : (const void *)conv_wino_kernel<false>;
     if (int rc = ensure_dynamic_lds(fn, LDS_BYTES)) return rc;
-    const bool prof = prof_enabled(), v2 = !opt(OPT_WINO_V1) && conv_wino2_eligible(a);
+    const bool prof = prof_enabled(), v2 = a.ksplit > 1 || (!opt(OPT_WINO_V1) && conv_wino2_eligible(a));
+    IPDM_REQUIRE(a.ksplit == 1 || conv_wino2_eligible(a), "conv2d_wino: this layer cannot be split into %d K slices", a.ksplit);
     if (prof) prof_before(v2 ? 5 : 3, st);
     if (v2) {
         if (int rc = conv2d_wino2_launch(a, st)) return rc;

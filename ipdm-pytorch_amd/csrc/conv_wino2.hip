@@ -63,13 +63,15 @@ constexpr size_t LDS_BYTES = (size_t)(2 * V_FLOATS + XCH_FLOATS + NW * XWAVE) * 
 static_assert(LDS_BYTES <= 160 * 1024, "conv_wino2: LDS budget exceeded");
 static_assert(128 <= XWAVE, "conv_wino2: the statistics staging aliases the wave's scratch");
 
-struct TileId { int n, oy0, ox0, co0; };
+struct TileId { int n, oy0, ox0, co0, ks; };      // ks: slice of the K (input channel) range, ConvArgs::ksplit
 
 __host__ __device__ constexpr int row_slot(int i) { return i ^ (i >> 1); }      // rows of the transform domain in the order 0, 1, 3, 2
 
-__device__ inline TileId decode_tile(const ConvArgs &a, int tile)
+__device__ inline TileId decode_tile(const ConvArgs &a, int item)
 {
     TileId t;
+    t.ks = item % a.ksplit;                            // the K slices of one tile are neighbours in the schedule
+    const int tile = item / a.ksplit;
     const int co_t = tile % a.co_tiles;
     int rest = tile / a.co_tiles;
     const int tx = rest % a.tiles_x;
@@ -105,7 +107,10 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     auto tile_of = [&](int k) { return k * G + (local + 5 * k) % G; };
     const int n_my = rounds == 0 ? 0 : (tile_of(rounds - 1) < ntiles ? rounds : rounds - 1);
     const int Ctot = a.C1 + a.C2;
-    const int nchunks = Ctot / KC;                       // launcher: Ctot % KC == 0, C1 % KC == 0, nchunks >= 2
+    // chunks per schedule item: the whole channel range, or one of a.ksplit equal slices of it (K split: the item's partial
+    // sums go to slice ks of a.out = the split workspace, no bias / residual / statistics; conv_ws.hip's combine pass folds
+    // the slices in ascending order)
+    const int nchunks = Ctot / KC / a.ksplit;            // launcher: Ctot % (KC * ksplit) == 0, C1 % KC == 0, nchunks >= 2
     const int S = n_my * nchunks;
     const int plane_bytes = a.Hs * a.Ws * 4;
     if (S == 0) return;
@@ -115,7 +120,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     const int tyw = swave & 1, cg = swave >> 1;
     const int q = lane & 3;                                              // the lane's channel inside the group
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)a.w, 0, 2 * nchunks * 2 * a.co_tiles * U_CHUNK_FLOATS * 4, 0x00020000);      // (a.co_tiles counts 128-cout tiles)
+        (void *)a.w, 0, 2 * (Ctot / KC) * 2 * a.co_tiles * U_CHUNK_FLOATS * 4, 0x00020000);      // (a.co_tiles counts 128-cout tiles)
     // slot u = (lane >> 2) + 16 j  ->  (row r, 4-float part) of the lane's channel; 36 of the 48 slots exist
     int lconst[3], xoff[3];
 #pragma unroll
@@ -141,7 +146,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         }
     }
     // tile descriptors: issue side (g_*: the tile whose chunks are being LOADED), activation side (a_*: one chunk behind)
-    int g_n = 0, g_co = 0, g_oy = 0, g_ox = 0;
+    int g_n = 0, g_co = 0, g_oy = 0, g_ox = 0, g_ks = 0;
     const float *g_src1 = a.x1, *g_src2 = a.x2 ? a.x2 : a.x1;
     bool g_bord = false;
     int vo[3] = {lconst[0], lconst[1], lconst[2]}, g_so = 0;             // NCHW offsets of the tile being loaded
@@ -152,7 +157,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     auto describe = [&](int k) __attribute__((always_inline)) {
         const TileId tl = decode_tile(a, tile_of(k));
         const int iy0 = tl.oy0 - 1 + 2 * tyw, ix0 = tl.ox0 - 1;
-        g_n = tl.n; g_co = tl.co0 / BN; g_oy = tl.oy0; g_ox = tl.ox0;
+        g_n = tl.n; g_co = tl.co0 / BN; g_oy = tl.oy0; g_ox = tl.ox0; g_ks = tl.ks;
         g_src1 = a.x1 + (size_t)tl.n * a.C1 * (plane_bytes / 4);
         g_src2 = a.x2 ? a.x2 + (size_t)tl.n * a.C2 * (plane_bytes / 4) : g_src1;
         g_bord = tl.oy0 - 1 < 0 || tl.ox0 - 1 < 0 || tl.oy0 + TH + 1 > a.H || tl.ox0 + TW + 1 > a.W;
@@ -203,9 +208,10 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
                 //  0: tools/ubench/oob_probe.hip; either way those elements are masked by g_vm)
             }
         }
+        const bool starts_in_x1 = g_ks * nchunks * KC < a.C1;      // (a K slice may begin in the skip half of a concat: NCHW)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) va[j] = PLANAR ? vop[PLANAR ? j : 0] : vo[j];      // chunk 0 of a tile is x1's
-        g_sa = PLANAR ? g_sop : g_so;
+        for (int j = 0; j < 3; ++j) va[j] = (PLANAR && starts_in_x1) ? vop[PLANAR ? j : 0] : vo[j];
+        g_sa = (PLANAR && starts_in_x1) ? g_sop : g_so;
     };
     struct Raw { f32x4 v[3]; float sc, sh; bool planar; };
     Raw raw;
@@ -214,7 +220,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     // every iteration issues the same loads, needed or not (past the end of the stream they re-read chunks of the last tile:
     // valid addresses, results unused): with conditional issue the waitcnt pass has to assume the shortest path
     auto issue_raw = [&](int ch) __attribute__((always_inline)) {
-        const int c0 = ch * KC;
+        const int c0 = (g_ks * nchunks + ch) * KC;           // (g_*: the item whose chunks are being loaded)
         const bool from1 = c0 < a.C1;
         const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(from1 ? g_src1 : g_src2), 0, (from1 ? a.C1 : a.C2) * plane_bytes, 0x00020000);
         const int cb = ((from1 ? c0 : c0 - a.C1) + 4 * cg) * plane_bytes;
@@ -346,17 +352,17 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     };
     const int u_voff = ((((8 * ih) * 2 + (hq & 1)) * 2 + lk) * 32 + l31) * 16;        // bytes; + e * 2048 + (8-channel chunk, 64-cout tile) image
     const int b_off = (((8 * ih) * 2 + lk) * 32 + l31) * 4;                           // floats; + e * 256 (+ stage)
-    int w_co = 0;
+    int w_co = 0, w_q0 = 0;                                // cout tile / first 8-channel chunk of the item whose weights are being loaded
     // q8 = 8-channel chunk (2 * chunk + sub-chunk)
     auto issue_u = [&](int e, int q8) __attribute__((always_inline)) {
-        const int w_soff = (q8 * 2 * a.co_tiles + 2 * w_co + (hq >> 1)) * (U_CHUNK_FLOATS * 4) + e * 2048;
+        const int w_soff = ((w_q0 + q8) * 2 * a.co_tiles + 2 * w_co + (hq >> 1)) * (U_CHUNK_FLOATS * 4) + e * 2048;
         ua[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, u_voff, w_soff, 0));
     };
 
     // ---------------------------------------------------------------- prologue: tile 0, chunk 0 staged, chunk 1 in flight
     describe(0);
     a_vm = g_vm; a_vmp = g_vmp; a_lsh = g_lsh; a_bord = g_bord;
-    w_co = g_co;
+    w_co = g_co; w_q0 = 2 * g_ks * nchunks;
 #pragma unroll
     for (int e = 0; e < 8; ++e) issue_u(e, 0);
     issue_raw(0);
@@ -374,7 +380,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     const unsigned long long st_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
 #define IPDM_STAMP(slot) if (stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[slot] += now_ - st_t; st_t = now_; __builtin_amdgcn_sched_barrier(0); }
     if (stamp) st_t = st_begin;
-    TileId cur = {g_n, g_oy, g_ox, g_co * BN};
+    TileId cur = {g_n, g_oy, g_ox, g_co * BN, g_ks};
     // One chunk: stage chunk s + 1 (activation -> scratch -> patch), multiply chunk s, transform chunk s + 1 into the other V
     // stage, barrier.  The first chunk of a tile STARTS its accumulators (C = 0 in the first MFMA of each), so that they are
     // dead from the output transform to the next tile.
@@ -408,7 +414,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
                 } else if (!(IPDM_WINO2_KO & 2)) {
                     read_patch();                          // patch(s + 1) (behind the first operand: the LDS returns in order)
                 }
-                if (ch1 == 0) w_co = g_co;                 // from here on the weights loaded belong to the tile described last
+                if (ch1 == 0) { w_co = g_co; w_q0 = 2 * g_ks * nchunks; }      // from here on the weights loaded belong to the item described last
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -442,15 +448,15 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         chunk(std::true_type{}, 0);
         for (int ch = 1; ch < nchunks; ++ch) chunk(std::false_type{}, ch);
         // ---------------------------------------------------------------- tile epilogue
-        if (IPDM_WINO2_KO & 4) { cur = TileId{g_n, g_oy, g_ox, g_co * BN}; continue; }
+        if (IPDM_WINO2_KO & 4) { cur = TileId{g_n, g_oy, g_ox, g_co * BN, g_ks}; continue; }
         // + bias through position (1, 1) (accumulator 5 of the ih = 0 waves), whose output coefficients are all 1
         if (ih == 0) {
             acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb, 1.0f, acc[5], 0, 0, 0);
             if (k + 1 < n_my) fetch_bias(g_co * BN);        // (describe(k + 1) ran two chunks ago)
         }
         const TileId t = cur;
-        cur = TileId{g_n, g_oy, g_ox, g_co * BN};
-        const size_t sample = (size_t)t.n * a.Cout * out_plane;
+        cur = TileId{g_n, g_oy, g_ox, g_co * BN, g_ks};
+        const size_t sample = ((size_t)t.ks * a.B + t.n) * a.Cout * out_plane;      // (ks > 0 only with a.out = the split workspace [ksplit][B,Cout,Ho,Wo])
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * out_plane * 4, 0x00020000);
         // (no residual: zero records -- the loads below return 0 and the add stays unconditional)
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0,
@@ -578,21 +584,42 @@ namespace ipdm {
 // same output transform -- so their results are bit-identical (tests/test_gpu_parity.py::test_wino_kernels_bit_identical) and
 // the choice may look at the batch: launches whose 128-cout tiles would leave a quarter of the chip idle (a lone slice on the
 // mid-resolution levels: 256->256 @64x64 is 64 tiles, 0.64x the round-3 kernel's time on its 128) stay on the 64-cout tiles.
+// K-split launches (a.ksplit > 1) exist in this kernel only.
 bool conv_wino2_eligible(const ConvArgs &a)
 {
     const int Ctot = a.C1 + a.C2;
     if (a.Cout % BN || Ctot % KC || (a.C2 && a.C1 % KC) || Ctot < 2 * KC) return false;
+    if (a.ksplit > 1) return Ctot % (KC * a.ksplit) == 0 && Ctot / (KC * a.ksplit) >= 2;
     const long ntiles = (long)cdiv(a.Ho, TH) * cdiv(a.Wo, TW) * (a.Cout / BN) * a.B;
     return ntiles >= opt(OPT_WINO2_MIN_TILES);      // (192; a per-call option so that tests can drive small shapes through this kernel)
 }
 
-// `a`: the arguments as conv2d_wino_launch prepared them (a.w = the Winograd-domain weights, tiles_x / tiles_y for 4 x 32-pixel
-// tiles), conv_wino2_eligible(a)
+// K slices for the layers the direct tiling splits (conv_ws_split(a) > 1: <= 16 tiles of 8x32x128 per sample, a rule of the
+// layer alone -- a split changes the summation order, so it must not depend on the batch): at most FOUR slices, each of at
+// least two 16-channel chunks (the pipeline's minimum).  Measured on 256->256 @63x29 (profiles/r04_wino_ksplit.txt): B = 8
+// 0.119 / 0.138 / 0.184 ms with 2 / 4 / 8 slices (every slice pays an output transform; the K-split direct kernel: 0.197), a
+// lone slice 0.057 / 0.044 / 0.044 ms (direct: 0.040).  0: this layer cannot be split here.
+int conv_wino_split(const ConvArgs &a)
+{
+    const int Ctot = a.C1 + a.C2;
+    if (a.Cout % BN || Ctot % KC || (a.C2 && a.C1 % KC)) return 0;
+    const int nch = Ctot / KC;
+    for (int S = 4; S >= 2; S >>= 1)
+        if (nch % S == 0 && nch / S >= 2) return S;
+    return 0;
+}
+
+// `prepared`: the arguments as conv2d_wino_launch prepared them (a.w = the Winograd-domain weights, tiles_x / tiles_y for
+// 4 x 32-pixel tiles, ksplit), conv_wino2_eligible(prepared)
 int conv2d_wino2_launch(const ConvArgs &prepared, hipStream_t st)
 {
     ConvArgs a = prepared;
     a.co_tiles = a.Cout / BN;
-    const long ntiles = (long)a.tiles_x * a.tiles_y * a.co_tiles * a.B;
+    if (a.ksplit < 1) a.ksplit = 1;
+    const long ntiles = (long)a.tiles_x * a.tiles_y * a.co_tiles * a.B * a.ksplit;
+    IPDM_REQUIRE(ntiles < (1L << 31), "conv2d_wino2: too many tiles");
+    IPDM_REQUIRE(a.ksplit == 1 || (!a.bias && !a.res && !a.stats), "conv2d_wino2: a K-split launch writes bare partial sums");
+    IPDM_REQUIRE((long)a.ksplit * a.B * a.Cout * a.Ho * a.Wo < (1L << 40), "conv2d_wino2: split workspace too large");
     const int cus = device_cu_count();
     long G = ntiles < cus ? ntiles : cus;
     G = (G + 7) / 8 * 8;

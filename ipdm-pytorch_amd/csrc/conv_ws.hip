@@ -744,7 +744,7 @@ bool conv_up2_eligible(const ConvArgs &a)
 int conv_ws_stats_rows(const ConvArgs &a)
 {
     if (conv_up2_eligible(a)) return 4 * a.Hs * cdiv(a.Ws, 32);
-    if (a.split_ws && conv_ws_split(a) > 1 && !conv_wino_eligible(a)) return cdiv((long)a.Ho * a.Wo, SPLIT_PIX);
+    if (a.split_ws && conv_split(a) > 1) return cdiv((long)a.Ho * a.Wo, SPLIT_PIX);      // the combine pass writes them (either kernel)
     return a.Ho * cdiv(a.Wo, 32);      // one row per pixel row and 32-pixel tile column: independent of the tile variant
 }
 
@@ -796,12 +796,12 @@ int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
         if (a.w_interleave == 4) return launch_ws<2, 1, 4, 2, 8>(k, st, 1);
         return launch_ws<2, 1, 2, 4, 8>(k, st, 1);
     }
-    if (conv_wino_eligible(a)) return conv2d_wino_launch(a, st);      // the Winograd-domain form (conv_wino.hip)
-    const int S = a.split_ws ? conv_ws_split(a) : 1;
-    if (S == 1) return conv2d_ws_dispatch(a, st);
+    const bool wino = conv_wino_eligible(a);                                 // the Winograd-domain form (conv_wino.hip / conv_wino2.hip)
+    const int S = a.split_ws ? conv_split(a) : 1;
+    if (S == 1) return wino ? conv2d_wino_launch(a, st) : conv2d_ws_dispatch(a, st);
     ConvArgs k = a;
     k.out = a.split_ws; k.bias = nullptr; k.res = nullptr; k.stats = nullptr; k.stats_rows = 0; k.ksplit = S;
-    if (int rc = conv2d_ws_dispatch(k, st)) return rc;
+    if (int rc = wino ? conv2d_wino_launch(k, st) : conv2d_ws_dispatch(k, st)) return rc;
     const int HW = a.Ho * a.Wo, rows = cdiv(HW, SPLIT_PIX);
     IPDM_REQUIRE(!a.stats || a.stats_rows == rows, "conv2d: statistics rows %d != %d (K split)", a.stats_rows, rows);
     hipLaunchKernelGGL(splitk_combine_kernel, dim3(rows, a.Cout, a.B), dim3(256), 0, st, a.split_ws, S, a.bias, a.res, a.out,

@@ -122,6 +122,7 @@ bool conv_up2_eligible(const ConvArgs &a);         // shape fields + w_up2 + w_i
 bool conv_wino_eligible(const ConvArgs &a);        // shape fields + w_wino decide
 bool conv_wino_shape_ok(int Cout, int Cin, int ks, int stride, int interleave);   // worth packing U for this layer
 int conv2d_wino_launch(const ConvArgs &a, hipStream_t st);
+int conv_wino_split(const ConvArgs &a);            // K slices conv_wino2 would cut a K-split layer into (0: it cannot)
 bool conv_wino2_eligible(const ConvArgs &a);       // ... of those, the layers the round-4 kernel takes (whole 128-cout tiles, 16-channel chunks)
 int conv2d_wino2_launch(const ConvArgs &prepared, hipStream_t st);   // conv_wino2.hip; called by conv2d_wino_launch
 // [Cin/8][Cout/64][xi 16][cout half][k parity][cout 32][k step] = the LDS image of one (chunk, cout tile)

@@ -92,7 +92,7 @@ def test_option_values_are_range_checked():
     graph key or a kernel's static limits must never see them."""
     from ipdm_pytorch_amd import _lib
     lib = _lib.lib()
-    for name, bad in (("conv_nm", 4), ("wino_split_min_tiles", -1), ("unet_transpose", 2), ("direct_max_cin", 4096), ("conv_split", 1),
+    for name, bad in (("conv_nm", 4), ("wino2_min_tiles", -1), ("unet_transpose", 2), ("direct_max_cin", 4096), ("conv_split", 1),
                       ("conv_no_wino", 7)):
         old = _lib.get_option(name)
         rc = lib.ipdm_set_option(name.encode(), bad)

@@ -294,6 +294,11 @@ def _conv_case(B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res, seed):
     got = out.cpu()
     err = (got - want).abs().max().item()
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, (B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res))
+    return got
+
+
+def _conv_case_out(case, seed):
+    return _conv_case(*case, seed=seed)
 
 
 @pytest.mark.parametrize("case", [
@@ -578,7 +583,8 @@ def test_conv_kernel_code_table():
         ((8, 64, 64, 3, 1, 512, 512), 1),        # 64-cout layers: no 128-cout tile
         ((8, 128, 144, 3, 1, 228, 500), 2),      # 128 + 16 concat of the proj UNet
         ((8, 128, 72, 3, 1, 228, 500), 1),       # Cin not a multiple of 16
-        ((8, 256, 256, 3, 1, 32, 32), 4),        # K-split layer (direct kernel + combine)
+        ((8, 256, 256, 3, 1, 32, 32), 9),        # K-split layer: K slices inside conv_wino2 + combine pass
+        ((8, 320, 256, 3, 1, 32, 32), 4),        # ... whose couts are off the 128-cout tile: the K-split direct kernel
         ((8, 768, 256, 1, 1, 64, 64), 3),        # qkv 1x1
         ((8, 128, 128, 3, 2, 512, 512), 3),      # Downsample
         ((8, 8, 8, 3, 1, 2000, 912), 5),         # narrow level
@@ -653,7 +659,8 @@ def test_wino128_fused_statistics_and_planar_reader():
     """conv_wino2 as the PRODUCER of fused GroupNorm statistics (conv A -> GroupNorm+SiLU -> conv B: d_mid, the rows and the
     result bit-equal to the 64-cout kernel's) and as the READER of a parity-planar x1 (the up2 -> concat -> conv chain)."""
     from ipdm_pytorch_amd import _lib
-    for case in [(2, 64, 48, 64, 128, 3, 1, True, 2, 128), (1, 128, 21, 57, 256, 3, 1, True, 2, 128), (2, 128, 26, 250, 128, 3, 1, True, 2, 128)]:
+    # (more than 16 direct tiles per sample for BOTH convolutions: K-split layers take different kernels under the two switches)
+    for case in [(2, 64, 80, 64, 128, 3, 1, True, 2, 128), (1, 128, 72, 57, 256, 3, 1, True, 2, 128), (2, 128, 26, 250, 128, 3, 1, True, 2, 128)]:
         res = []
         for v1 in (1, 0):
             with _lib.option("wino_v1", v1), _lib.option("wino2_min_tiles", 1):
@@ -681,15 +688,28 @@ def test_direct_fallback_of_the_winograd_layers():
         test_upsample_conv_parity_form((2, 64, 33, 47, 64, 0, 64, 3, 2))
 
 
-def test_k_split_layers_on_the_winograd_kernel_opt_in():
-    """Option wino_split_min_tiles (off by default: DESIGN 8): layers the direct tiling splits along K take the Winograd
-    kernel instead -- same tolerance, same fused statistics rows as every other producer."""
+def test_k_split_layers_on_the_winograd_kernel():
+    """Layers the direct tiling splits along K (<= 16 tiles of 8x32x128 per sample) run in the Winograd domain with the K
+    slices INSIDE conv_wino2 (round 4; a rule of the layer alone, so batch 1 and batch 8 take the same slices): same
+    tolerance, same combine pass (bias, residual, statistics rows) as the K-split direct kernel, which stays the path of the
+    layers conv_wino2 cannot slice (Cout or Cin off its tile sizes) and of the wino_v1 / conv_no_wino arms."""
     from ipdm_pytorch_amd import _lib
-    with _lib.option("wino_split_min_tiles", 16):
-        for i, case in enumerate([(1, 256, 0, 32, 32, 32, 32, 256, 3, 1, 2, True), (1, 256, 256, 16, 24, 16, 24, 256, 3, 1, 2, False),
-                                  (2, 256, 0, 63, 29, 63, 29, 256, 3, 1, 2, True)]):
-            _conv_case(*case, seed=7100 + i)
-        test_fused_groupnorm_statistics_chain((1, 256, 32, 32, 256, 3, 1, True, 2, 64))
+    code = _lib.lib().ipdm_conv_kernel_code
+    assert code(1, 256, 256, 3, 1, 32, 32) == 9 and code(8, 256, 256, 3, 1, 32, 32) == 9 and code(8, 256, 512, 3, 1, 63, 29) == 9
+    assert code(1, 192, 256, 3, 1, 32, 32) == 4                      # 192 couts: no whole 128-cout tiles -> K-split direct kernel
+    with _lib.option("conv_no_wino", 1):
+        assert code(8, 256, 256, 3, 1, 32, 32) == 4
+    for i, case in enumerate([(1, 256, 0, 32, 32, 32, 32, 256, 3, 1, 2, True), (1, 256, 256, 16, 24, 16, 24, 256, 3, 1, 2, False),
+                              (2, 256, 0, 63, 29, 63, 29, 256, 3, 1, 2, True), (8, 256, 128, 29, 63, 29, 63, 256, 3, 1, 1, True),
+                              (1, 128, 0, 20, 36, 20, 36, 128, 3, 1, 0, False)]):
+        _conv_case(*case, seed=7100 + i)
+    for case in [(1, 256, 32, 32, 256, 3, 1, True, 2, 64), (2, 256, 29, 63, 256, 3, 1, True, 2, 128)]:
+        d_mid, d_out, rows = _conv_gn_conv(case)
+        assert rows == -(-case[2] * case[3] // 2048), rows                # the combine pass's statistics rows (SPLIT_PIX pixels each)
+    # a batch is its slices: the K split does not look at the batch
+    one = _conv_case_out((1, 256, 0, 32, 32, 32, 32, 256, 3, 1, 2, True), 7100)
+    four = _conv_case_out((4, 256, 0, 32, 32, 32, 32, 256, 3, 1, 2, True), 7100)
+    assert torch.equal(one[0], four[0])
 
 
 def test_narrow_convolutions_on_the_16_cout_mfma_opt_in():

@@ -109,6 +109,11 @@ def main():
     bench(8, 128, 0, 512, 512, 128, 2, True)
     if quick:
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "ksplit":      # the K-split layers: K slices inside conv_wino2 vs the K-split direct kernel
+        for B in (1, 8):
+            for shp in ((256, 0, 32, 32), (256, 0, 63, 29), (256, 256, 63, 29), (256, 256, 32, 32), (256, 128, 63, 29)):
+                bench(B, shp[0], shp[1], shp[2], shp[3], 256, 2, shp[1] == 0)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         for B in (1, 2, 4, 8):
             for shp in ((128, 128, 128), (256, 128, 128), (256, 64, 64), (128, 250, 114), (256, 125, 57), (256, 250, 114)):
