@@ -566,6 +566,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
             }
             __builtin_amdgcn_wave_barrier();
         }
+        asm volatile("s_nop 7");      // (store data registers vs the first VALU write of the next tile, across the back edge: conv_pw.hip)
         IPDM_STAMP(4)
     }
     if (stamp && tid == 0) {
