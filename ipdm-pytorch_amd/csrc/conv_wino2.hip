@@ -501,7 +501,9 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
                 *reinterpret_cast<f32x4 *>(xo + p * 256) = f32x4{hi0[0], hi0[1], hi1[0], hi1[1]};
             }
         }
+        IPDM_STAMP(5)
         __syncthreads();                                   // E: both halves of every (tile, cout) are in LDS
+        IPDM_STAMP(6)
         f32x4 gotv[8];                                     // partner's {T[0] c, T[0] c+1, T[1] c, T[1] c+1} of every pair
 #pragma unroll
         for (int i = 0; i < 8; ++i) gotv[i] = *reinterpret_cast<const f32x4 *>(xr2 + i * 256);
@@ -572,7 +574,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     if (stamp && tid == 0) {
         unsigned long long *d = a.dbg_buf + (size_t)blockIdx.x * 8;
         d[0] = st_acc[1]; d[1] = st_acc[4]; d[2] = st_acc[3]; d[3] = __builtin_amdgcn_s_memtime() - st_begin;
-        d[4] = st_acc[0]; d[5] = st_acc[2]; d[6] = 0; d[7] = 0;
+        d[4] = st_acc[0]; d[5] = st_acc[2]; d[6] = st_acc[5]; d[7] = st_acc[6];
     }
 #undef IPDM_STAMP
 }
