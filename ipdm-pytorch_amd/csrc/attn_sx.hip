@@ -283,12 +283,12 @@ __global__ void __launch_bounds__(768) attention_sx_kernel(const float *__restri
 
 namespace ipdm {
 
-size_t attention_sx_scratch_floats(int B, int heads, int T)
+static size_t attention_sx_scratch_floats_impl(int B, int heads, int T)
 {
     return (size_t)B * heads * cdiv(T, KV) * STAGE / 2;        // bf16 tile images, counted in floats
 }
 
-int attention_sx_launch(const float *qkv, float *scratch, float *out, int B, int heads, int T, float scale, hipStream_t st)
+static int attention_sx_launch_impl(const float *qkv, float *scratch, float *out, int B, int heads, int T, float scale, hipStream_t st)
 {
     IPDM_REQUIRE(scratch, "attention (split-bf16): no scratch for the pre-split K/V pieces");
     constexpr size_t lds = (size_t)2 * STAGE * sizeof(unsigned short);
@@ -301,3 +301,10 @@ int attention_sx_launch(const float *qkv, float *scratch, float *out, int B, int
 }
 
 }  // namespace ipdm
+
+// entry points of libipdm_hip_optin.so (csrc/optin.hip)
+extern "C" size_t ipdm_optin_attention_sx_scratch_floats(int B, int heads, int T) { return ipdm::attention_sx_scratch_floats_impl(B, heads, T); }
+extern "C" int ipdm_optin_attention_sx_launch(const float *qkv, float *scratch, float *out, int B, int heads, int T, float scale, hipStream_t st)
+{
+    return ipdm::attention_sx_launch_impl(qkv, scratch, out, B, heads, T, scale, st);
+}

@@ -307,7 +307,7 @@ namespace ipdm {
 
 // Which narrow layers run here: stride 1, 3x3 or 1x1, whole groups of 4 input channels (<= 32, the concat boundary on a
 // group), 8..16 couts in whole groups of 4, NCHW sources.  A rule of the layer alone, never of the batch.
-bool conv_nm_eligible(const ConvArgs &a)
+static bool conv_nm_eligible_impl(const ConvArgs &a)
 {
     if (opt(OPT_CONV_NM) <= 0) return false;              // opt-in (see the header: no gain inside the network)
     const int Ctot = a.C1 + a.C2, g = Ctot / 4;
@@ -318,9 +318,9 @@ bool conv_nm_eligible(const ConvArgs &a)
     return !conv_direct_up2_eligible(a);
 }
 
-int conv2d_nm_launch(const ConvArgs &a, hipStream_t st)
+static int conv2d_nm_launch_impl(const ConvArgs &a, hipStream_t st)
 {
-    IPDM_REQUIRE(conv_nm_eligible(a), "conv2d_nm: layer not eligible");
+    IPDM_REQUIRE(conv_nm_eligible_impl(a), "conv2d_nm: layer not eligible");
     IPDM_REQUIRE(!a.stats || a.stats_rows == conv_direct_stats_rows(a), "conv2d_nm: statistics rows %d != %d", a.stats_rows, conv_direct_stats_rows(a));
     IPDM_REQUIRE((long)a.C1 * a.Hs * a.Ws < (1L << 29) && (long)(a.C2 + 1) * a.Hs * a.Ws < (1L << 29) && (long)a.Cout * a.Ho * a.Wo < (1L << 29),
                  "conv2d_nm: per-sample tensor exceeds the 2 GiB buffer-addressing range");
@@ -328,3 +328,7 @@ int conv2d_nm_launch(const ConvArgs &a, hipStream_t st)
 }
 
 }  // namespace ipdm
+
+// entry points of libipdm_hip_optin.so (csrc/optin.hip)
+extern "C" int ipdm_optin_conv_nm_eligible(const ipdm::ConvArgs *a) { return ipdm::conv_nm_eligible_impl(*a) ? 1 : 0; }
+extern "C" int ipdm_optin_conv2d_nm_launch(const ipdm::ConvArgs *a, hipStream_t st) { return ipdm::conv2d_nm_launch_impl(*a, st); }

@@ -344,7 +344,7 @@ namespace ipdm {
 int conv_sx_pieces(int interleave) { return interleave >= 100 ? interleave - 100 : 0; }
 
 // [Cout][Cin][3][3] f32 (host) -> [cout block 32][chunk 16][tap][piece][lane 64][8] bf16 (as uint16), zero padded
-void conv_sx_pack_weights(const float *w, int Cout, int Cin, int ns, std::vector<float> &packed, int &cin_pad, int &cout_pad)
+static void conv_sx_pack_weights_impl(const float *w, int Cout, int Cin, int ns, std::vector<float> &packed, int &cin_pad, int &cout_pad)
 {
     cin_pad = (Cin + SX_KC - 1) / SX_KC * SX_KC;
     cout_pad = (Cout + 31) / 32 * 32;
@@ -376,7 +376,7 @@ void conv_sx_pack_weights(const float *w, int Cout, int Cin, int ns, std::vector
     memcpy(packed.data(), out.data(), out.size() * 2);
 }
 
-int conv2d_sx_launch(const ConvArgs &a, hipStream_t st)
+static int conv2d_sx_launch_impl(const ConvArgs &a, hipStream_t st)
 {
     const int ns = conv_sx_pieces(a.w_interleave);
     IPDM_REQUIRE(a.ksize == 3 && a.stride == 1 && (ns == 2 || ns == 3), "conv2d(split): unsupported configuration");
@@ -394,3 +394,10 @@ int conv2d_sx_launch(const ConvArgs &a, hipStream_t st)
 }
 
 }  // namespace ipdm
+
+// entry points of libipdm_hip_optin.so (resolved by csrc/optin.hip of the product library when an opt-in mode is switched on)
+extern "C" void ipdm_optin_conv_sx_pack_weights(const float *w, int Cout, int Cin, int ns, std::vector<float> *packed, int *cin_pad, int *cout_pad)
+{
+    ipdm::conv_sx_pack_weights_impl(w, Cout, Cin, ns, *packed, *cin_pad, *cout_pad);
+}
+extern "C" int ipdm_optin_conv2d_sx_launch(const ipdm::ConvArgs *a, hipStream_t st) { return ipdm::conv2d_sx_launch_impl(*a, st); }

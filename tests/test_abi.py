@@ -100,3 +100,24 @@ def test_option_values_are_range_checked():
         assert _lib.get_option(name) == old
     with _lib.option("unet_transpose", 1), _lib.option("conv_split", 3):
         assert _lib.get_option("unet_transpose") == 1 and _lib.get_option("conv_split") == 3
+
+
+def test_product_library_carries_only_the_default_path():
+    """The opt-in kernels (split-bf16 convolution / attention, the 16-cout MFMA form of the narrow layers) live in a second
+    shared object, libipdm_hip_optin.so, which the product library loads only when an opt-in option asks for them
+    (csrc/optin.hip): none of their device code is in libipdm_hip.so, and the second library exports what optin.hip binds."""
+    import os
+    from ipdm_pytorch_amd import _lib
+    d = os.path.dirname(_lib.LIB_PATH)
+    prod = open(_lib.LIB_PATH, "rb").read()
+    optin_path = os.path.join(d, "libipdm_hip_optin.so")
+    assert os.path.isfile(optin_path)
+    optin = open(optin_path, "rb").read()
+    for kern in (b"conv_sx_kernel", b"conv_nm_kernel", b"attention_sx_kernel"):
+        assert kern not in prod and kern in optin, kern
+    for kern in (b"conv_wino2_kernel", b"conv_ws_kernel", b"attention_ws_kernel", b"conv_direct"):
+        assert kern in prod, kern
+    h = C.CDLL(_lib.LIB_PATH) and C.CDLL(optin_path)      # (its undefined references resolve against the product library)
+    for sym in ("ipdm_optin_conv_sx_pack_weights", "ipdm_optin_conv2d_sx_launch", "ipdm_optin_conv_nm_eligible",
+                "ipdm_optin_conv2d_nm_launch", "ipdm_optin_attention_sx_scratch_floats", "ipdm_optin_attention_sx_launch"):
+        assert getattr(h, sym) is not None

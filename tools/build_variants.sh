@@ -10,7 +10,7 @@ base=${src%.hip}
 for spec in "$@"; do
     tag=${spec%%:*}; flags=${spec#*:}
     hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-function ${flags//,/ } -c $src -o /tmp/${base}_${tag}.o
-    objs=$(ls *.o | grep -v "^${base}.o$")
-    hipcc --offload-arch=gfx950 -shared -fPIC -o ../libipdm_hip_${tag}.so $objs /tmp/${base}_${tag}.o
+    objs=$(ls *.o | grep -v -E "^(${base}|conv_nm|conv_sx|attn_sx)\.o$")      # (the product library's objects: the opt-in kernels are a second .so)
+    hipcc --offload-arch=gfx950 -shared -fPIC -o ../libipdm_hip_${tag}.so $objs /tmp/${base}_${tag}.o -ldl
     echo "built ../libipdm_hip_${tag}.so ($flags)"
 done
