@@ -672,6 +672,22 @@ def test_wino128_fused_statistics_and_planar_reader():
                 test_upsample_conv_parity_form(case)
 
 
+def test_wino2_run_to_run_determinism():
+    """conv_wino2 under repetition (tools/wino_stress.py with fewer rounds): launches with one tile per workgroup (waves end
+    right behind their last stores), many-round launches, K slices, odd sizes -- every run bit-equal to the first and to the
+    64-cout kernel.  (The shelved 1x1 experiment on the same structure, tools/experiments/conv_pw.hip, failed exactly this.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wino_stress", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                              "tools", "wino_stress.py"))
+    ws = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ws)
+    bad = 0
+    for case in [(1, 128, 0, 72, 64, 128, 2, True), (2, 128, 0, 100, 96, 256, 2, False), (1, 256, 0, 32, 32, 256, 2, True),
+                 (1, 128, 16, 61, 129, 128, 1, True)]:
+        bad += ws.stress(*case, reps=12)
+    assert bad == 0
+
+
 def test_direct_fallback_of_the_winograd_layers():
     """conv_no_wino (per call; bench.py's '-nowino' mode): the layers the Winograd kernels take by default on the direct
     implicit-GEMM kernel (conv_ws) -- plain, concat, fused-statistics producer, parity-planar reader -- so that the shipped
