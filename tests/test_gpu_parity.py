@@ -804,6 +804,7 @@ UP2_CASES = [
     (1, 8, 20, 70, 8, 0, 8, 1, 1),                # 8 channels (the CO = 8 instantiation), 1x1 reader
     (1, 4, 9, 11, 4, 0, 4, 3, 0),                 # 4 channels: not eligible, 3x3 form with nearest addressing
     (1, 256, 4, 4, 256, 0, 256, 3, 1),            # 256 channels at 8x8: reader with a K split
+    (1, 256, 8, 8, 256, 256, 256, 3, 2),          # ... K slices inside conv_wino2 over cat(parity-planar, NCHW skip): slices 2, 3 begin in the skip half
     (1, 128, 228, 500, 128, 16, 16, 3, 2),        # production size (transposed sinogram level 500x228 -> 1000x456) and its 144 -> 16 reader
     (1, 128, 40, 72, 128, 64, 128, 3, 2),         # Winograd-domain reader of a parity-planar source, concatenated skip (80x144)
     (2, 64, 33, 47, 64, 0, 64, 3, 2),             # ... ragged tiles on both axes (66x94), border tiles on all sides
