@@ -450,7 +450,10 @@ int conv_direct_stats_rows(const ConvArgs &a) { return cdiv(a.Wo, DT_W) * cdiv(a
 // as extra K chunks?  Narrow levels only: 8 or 16 couts on the direct kernel, NCHW input, no residual of its own.
 bool conv_direct_skip_ok(const ConvArgs &a)
 {
-    if (opt(OPT_CONV_NO_DIRECT) || opt(OPT_DIRECT_NO_SKIP_FUSE) || opt(OPT_CONV_NM) > 0) return false;
+    // (round 4: no longer switched off by conv_nm -- that coupling was the whole "paradox" of the 16-cout MFMA kernel: with the
+    //  option on, the 16->16 layers ran 1.11-1.16x faster IN the network too, and every narrow block paid for its shortcut as
+    //  a launch of its own again; a layer that carries a fused shortcut stays on this kernel either way)
+    if (opt(OPT_CONV_NO_DIRECT) || opt(OPT_DIRECT_NO_SKIP_FUSE)) return false;
     return conv_direct_eligible(a) && a.ksize == 3 && a.stride == 1 && !a.upsample && !a.x1_planar && !a.C2 && !a.res && a.Cout > 4 && a.Cout <= 16 &&
            a.sk_C1 > 0 && a.sk_C1 + a.sk_C2 <= opt(OPT_DIRECT_MAX_CIN) && a.sk_cout_pad >= 16 && !conv_direct_up2_eligible(a);
 }
