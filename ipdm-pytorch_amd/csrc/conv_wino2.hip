@@ -58,7 +58,7 @@ constexpr int V_FLOATS = 2 * VH_FLOATS;                // a stage: both sub-chun
 constexpr int U_CHUNK_FLOATS = 16 * 2 * 2 * 32 * 4;    // packed weights of one (8-channel chunk, 64-cout tile)
 constexpr int XCH_FLOATS = NW * 8 * 64 * 4;            // per wave: 8 x (64 lanes x 16 bytes)
 constexpr int XP = 40;                                 // scratch row pitch (34 window columns; planar: columns up to 39)
-constexpr int XWAVE = 16 * XP + 64 * 4 + 8;            // per wave: 16 row segments + a dump slot per lane
+constexpr int XWAVE = 12 * XP + 64 * 4 + 8;            // per wave: 12 row segments (2 channels x 6 window rows) + a dump slot per lane
 constexpr size_t LDS_BYTES = (size_t)(2 * V_FLOATS + XCH_FLOATS + NW * XWAVE) * sizeof(float);
 static_assert(LDS_BYTES <= 160 * 1024, "conv_wino2: LDS budget exceeded");
 static_assert(128 <= XWAVE, "conv_wino2: the statistics staging aliases the wave's scratch");
@@ -116,47 +116,49 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     if (S == 0) return;
 
     // =============================================================================== staging role
-    // wave w: tile row w & 1 (4 input rows x 34 columns of the 16 tiles of that row), channels 4 (w >> 1) .. +3 of the 16-channel chunk
-    const int tyw = swave & 1, cg = swave >> 1;
-    const int q = lane & 3;                                              // the lane's channel inside the group
+    // wave w: channels 2 w, 2 w + 1 of the 16-channel chunk, ALL six window rows of the tile (both tile rows: 6 x 34 values per
+    // channel) -- every window element is loaded and activated once per workgroup (as (tile row, 4 channels) per wave, rows 2
+    // and 3 of the window were staged twice: 3 loads and 12 activations per lane and chunk instead of 2 and 8)
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)a.w, 0, 2 * (Ctot / KC) * 2 * a.co_tiles * U_CHUNK_FLOATS * 4, 0x00020000);      // (a.co_tiles counts 128-cout tiles)
-    // slot u = (lane >> 2) + 16 j  ->  (row r, 4-float part) of the lane's channel; 36 of the 48 slots exist
-    int lconst[3], xoff[3];
+    // slot u = lane + 64 j  ->  (channel cc, row r, 4-float part); 108 of the 128 slots exist (planar x1: 120)
+    int lconst[2], xoff[2], gnoff[2];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int u = (lane >> 2) + 16 * j, r = u / 9, part = u - r * 9;
-        const bool v = u < 36;
-        lconst[j] = v ? (r * a.Ws + 4 * part) * 4 + q * plane_bytes : OOB;
-        xoff[j] = v ? (q * 4 + r) * XP + (PLANAR ? 2 : 4) * part : 16 * XP + lane * (PLANAR ? 2 : 4);
+    for (int j = 0; j < 2; ++j) {
+        const int u = lane + 64 * j, cc = u / 54, r = (u - cc * 54) / 9, part = u - cc * 54 - r * 9;
+        const bool v = u < 108;
+        lconst[j] = v ? (r * a.Ws + 4 * part) * 4 + cc * plane_bytes : OOB;
+        xoff[j] = v ? (cc * 6 + r) * XP + (PLANAR ? 2 : 4) * part : 12 * XP + lane * (PLANAR ? 2 : 4);
+        gnoff[j] = (v ? cc : 0) * 4;
     }
     // parity-planar x1 ([ch][row & 1][col & 1][H/2][W/2]): 10 lanes per window row (5 x 16 bytes per plane), the scratch row
     // de-interleaved [even window columns: 20][odd: 20] (conv_wino.hip has the reasoning)
-    int lconstp[PLANAR ? 3 : 1], xoffp[PLANAR ? 3 : 1];
+    int lconstp[PLANAR ? 2 : 1], xoffp[PLANAR ? 2 : 1], gnoffp[PLANAR ? 2 : 1];
     const int h2 = a.Hs >> 1, w2 = a.Ws >> 1;
     if (PLANAR) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int u = (lane >> 2) + 16 * j, r = u / 10, part = u - r * 10;
-            const bool v = u < 40;
-            const int px = part < 5 ? 1 : 0, py = (r + 1) & 1, yo = r == 0 ? -1 : (r == 3 ? 1 : 0);
+        for (int j = 0; j < 2; ++j) {
+            const int u = lane + 64 * j, cc = u / 60, r = (u - cc * 60) / 10, part = u - cc * 60 - r * 10;
+            const bool v = u < 120;
+            const int px = part < 5 ? 1 : 0, py = (r + 1) & 1, yo = (r + 1) / 2 - 1;      // window row r = image row oy0 - 1 + r, oy0 even
             const int xo = px ? 4 * part - 1 : 4 * (part - 5);
-            lconstp[PLANAR ? j : 0] = v ? (((py * 2 + px) * h2 + yo) * w2 + xo) * 4 + q * plane_bytes : OOB;
-            xoffp[PLANAR ? j : 0] = v ? (q * 4 + r) * XP + (px ? 4 * part : 20 + 4 * (part - 5)) : 16 * XP + lane * 4;
+            lconstp[PLANAR ? j : 0] = v ? (((py * 2 + px) * h2 + yo) * w2 + xo) * 4 + cc * plane_bytes : OOB;
+            xoffp[PLANAR ? j : 0] = v ? (cc * 6 + r) * XP + (px ? 4 * part : 20 + 4 * (part - 5)) : 12 * XP + lane * 4;
+            gnoffp[PLANAR ? j : 0] = (v ? cc : 0) * 4;
         }
     }
     // tile descriptors: issue side (g_*: the tile whose chunks are being LOADED), activation side (a_*: one chunk behind)
     int g_n = 0, g_co = 0, g_oy = 0, g_ox = 0, g_ks = 0;
     const float *g_src1 = a.x1, *g_src2 = a.x2 ? a.x2 : a.x1;
     bool g_bord = false;
-    int vo[3] = {lconst[0], lconst[1], lconst[2]}, g_so = 0;             // NCHW offsets of the tile being loaded
-    int va[3] = {lconst[0], lconst[1], lconst[2]}, g_sa = 0;             // the offsets the loads use (planar x1 / NCHW)
-    int vop[PLANAR ? 3 : 1] = {}, g_sop = 0;
-    unsigned g_vmp = 0xfffu, a_vmp = 0xfffu, g_vm = 0xfffu, g_lsh = 0, a_vm = 0xfffu, a_lsh = 0;
+    int vo[2] = {lconst[0], lconst[1]}, g_so = 0;                        // NCHW offsets of the tile being loaded
+    int va[2] = {lconst[0], lconst[1]}, g_sa = 0;                        // the offsets the loads use (planar x1 / NCHW)
+    int vop[PLANAR ? 2 : 1] = {}, g_sop = 0;
+    unsigned g_vmp = 0xffu, a_vmp = 0xffu, g_vm = 0xffu, g_lsh = 0, a_vm = 0xffu, a_lsh = 0;
     bool a_bord = false;
     auto describe = [&](int k) __attribute__((always_inline)) {
         const TileId tl = decode_tile(a, tile_of(k));
-        const int iy0 = tl.oy0 - 1 + 2 * tyw, ix0 = tl.ox0 - 1;
+        const int iy0 = tl.oy0 - 1, ix0 = tl.ox0 - 1;
         g_n = tl.n; g_co = tl.co0 / BN; g_oy = tl.oy0; g_ox = tl.ox0; g_ks = tl.ks;
         g_src1 = a.x1 + (size_t)tl.n * a.C1 * (plane_bytes / 4);
         g_src2 = a.x2 ? a.x2 + (size_t)tl.n * a.C2 * (plane_bytes / 4) : g_src1;
@@ -164,20 +166,20 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         const int g_base = (iy0 * a.Ws + ix0) * 4;
         g_so = g_bord ? 0 : g_base;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) vo[j] = lconst[j];
+        for (int j = 0; j < 2; ++j) vo[j] = lconst[j];
         if (PLANAR) {
-            const int basep = (((tl.oy0 >> 1) + tyw) * w2 + (tl.ox0 >> 1)) * 4;
+            const int basep = ((tl.oy0 >> 1) * w2 + (tl.ox0 >> 1)) * 4;
             g_sop = g_bord ? 0 : basep;
-            g_vmp = 0xfffu;
+            g_vmp = 0xffu;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) vop[PLANAR ? j : 0] = lconstp[PLANAR ? j : 0];
+            for (int j = 0; j < 2; ++j) vop[PLANAR ? j : 0] = lconstp[PLANAR ? j : 0];
             if (g_bord) {
                 g_vmp = 0;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int u = (lane >> 2) + 16 * j, r = u / 10, part = u - r * 10;
+                for (int j = 0; j < 2; ++j) {
+                    const int u = lane + 64 * j, cc = u / 60, r = (u - cc * 60) / 10, part = u - cc * 60 - r * 10;
                     const int c0 = part < 5 ? 8 * part : 8 * (part - 5) + 1;
-                    const bool rowok = u < 40 && iy0 + r >= 0 && iy0 + r < a.H;
+                    const bool rowok = u < 120 && iy0 + r >= 0 && iy0 + r < a.H;
                     vop[PLANAR ? j : 0] = rowok ? lconstp[PLANAR ? j : 0] + basep : OOB;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -190,9 +192,9 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         if (g_bord) {
             g_vm = 0; g_lsh = 0;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int u = (lane >> 2) + 16 * j, r = u / 9, part = u - r * 9;
-                const bool rowok = u < 36 && iy0 + r >= 0 && iy0 + r < a.H;
+            for (int j = 0; j < 2; ++j) {
+                const int u = lane + 64 * j, cc = u / 54, r = (u - cc * 54) / 9, part = u - cc * 54 - r * 9;
+                const bool rowok = u < 108 && iy0 + r >= 0 && iy0 + r < a.H;
                 // the 16 bytes of the leftmost part of an image row start one pixel before the row: shifted by one pixel and
                 // rotated back after the load (at the very first row they would start before the buffer)
                 const bool lsh = rowok && ix0 + 4 * part < 0;
@@ -210,10 +212,10 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         }
         const bool starts_in_x1 = g_ks * nchunks * KC < a.C1;      // (a K slice may begin in the skip half of a concat: NCHW)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) va[j] = (PLANAR && starts_in_x1) ? vop[PLANAR ? j : 0] : vo[j];
+        for (int j = 0; j < 2; ++j) va[j] = (PLANAR && starts_in_x1) ? vop[PLANAR ? j : 0] : vo[j];
         g_sa = (PLANAR && starts_in_x1) ? g_sop : g_so;
     };
-    struct Raw { f32x4 v[3]; float sc, sh; bool planar; };
+    struct Raw { f32x4 v[2]; float sc[2], sh[2]; bool planar; };
     Raw raw;
     const __amdgpu_buffer_rsrc_t gsc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.act ? a.gn_scale : a.out), 0, a.act ? (a.B * Ctot + 64) * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t gsh_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.act ? a.gn_shift : a.out), 0, a.act ? (a.B * Ctot + 64) * 4 : 0, 0x00020000);
@@ -223,68 +225,74 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         const int c0 = (g_ks * nchunks + ch) * KC;           // (g_*: the item whose chunks are being loaded)
         const bool from1 = c0 < a.C1;
         const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(from1 ? g_src1 : g_src2), 0, (from1 ? a.C1 : a.C2) * plane_bytes, 0x00020000);
-        const int cb = ((from1 ? c0 : c0 - a.C1) + 4 * cg) * plane_bytes;
+        const int cb = ((from1 ? c0 : c0 - a.C1) + 2 * swave) * plane_bytes;
         raw.planar = PLANAR && from1;
         if (PLANAR && c0 == a.C1) {  // (uniform, once per tile) only x1 is stored parity-planar; the skip half of a concat is NCHW
 #pragma unroll
-            for (int j = 0; j < 3; ++j) va[j] = vo[j];
+            for (int j = 0; j < 2; ++j) va[j] = vo[j];
             g_sa = g_so;
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 2; ++j)
             raw.v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, va[j], cb + g_sa, 0));
-        const int gso = (g_n * Ctot + c0 + 4 * cg) * 4;
-        raw.sc = bload(gsc_rsrc, q * 4, gso);
-        raw.sh = bload(gsh_rsrc, q * 4, gso);
-    };
-    // activate the 12 landed values, zero what lies outside the image, park them in the wave's scratch
-    auto activate = [&]() __attribute__((always_inline)) {
-        f32x2 d[6];
+        const int gso = (g_n * Ctot + c0 + 2 * swave) * 4;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { d[2 * j] = f32x2{raw.v[j][0], raw.v[j][1]}; d[2 * j + 1] = f32x2{raw.v[j][2], raw.v[j][3]}; }
+        for (int j = 0; j < 2; ++j) {                        // (the slot's channel: a per-lane offset; the planar slot map differs)
+            const int go = (PLANAR && raw.planar) ? gnoffp[PLANAR ? j : 0] : gnoff[j];
+            raw.sc[j] = bload(gsc_rsrc, go, gso);
+            raw.sh[j] = bload(gsh_rsrc, go, gso);
+        }
+    };
+    // activate the 8 landed values, zero what lies outside the image, park them in the wave's scratch
+    auto activate = [&]() __attribute__((always_inline)) {
+        f32x2 d[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { d[2 * j] = f32x2{raw.v[j][0], raw.v[j][1]}; d[2 * j + 1] = f32x2{raw.v[j][2], raw.v[j][3]}; }
         const bool pl = PLANAR && raw.planar;
         if (a_bord && !pl) {  // (uniform) undo the left-edge shift: {x0, x1, x2, x3} loaded from one pixel further right
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 2; ++j)
                 if (a_lsh >> j & 1) { d[2 * j + 1] = f32x2{d[2 * j][1], d[2 * j + 1][0]}; d[2 * j] = f32x2{0.0f, d[2 * j][0]}; }
         }
         if (a.act) {
-            const f32x2 sc2 = {raw.sc, raw.sc}, sh2 = {raw.sh, raw.sh};
 #pragma unroll
-            for (int e = 0; e < 6; ++e) d[e] = __builtin_elementwise_fma(d[e], sc2, sh2);
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 sc2 = {raw.sc[e >> 1], raw.sc[e >> 1]}, sh2 = {raw.sh[e >> 1], raw.sh[e >> 1]};
+                d[e] = __builtin_elementwise_fma(d[e], sc2, sh2);
+            }
             if (a.act == 2) {
-                f32x2 ex[6];
+                f32x2 ex[4];
 #pragma unroll
-                for (int e = 0; e < 6; ++e) ex[e] = d[e] * -1.4426950408889634f;
+                for (int e = 0; e < 4; ++e) ex[e] = d[e] * -1.4426950408889634f;
 #pragma unroll
-                for (int e = 0; e < 6; ++e) { ex[e][0] = __builtin_amdgcn_exp2f(ex[e][0]); ex[e][1] = __builtin_amdgcn_exp2f(ex[e][1]); }
+                for (int e = 0; e < 4; ++e) { ex[e][0] = __builtin_amdgcn_exp2f(ex[e][0]); ex[e][1] = __builtin_amdgcn_exp2f(ex[e][1]); }
 #pragma unroll
-                for (int e = 0; e < 6; ++e) ex[e] = ex[e] + 1.0f;
+                for (int e = 0; e < 4; ++e) ex[e] = ex[e] + 1.0f;
 #pragma unroll
-                for (int e = 0; e < 6; ++e) { ex[e][0] = __builtin_amdgcn_rcpf(ex[e][0]); ex[e][1] = __builtin_amdgcn_rcpf(ex[e][1]); }
+                for (int e = 0; e < 4; ++e) { ex[e][0] = __builtin_amdgcn_rcpf(ex[e][0]); ex[e][1] = __builtin_amdgcn_rcpf(ex[e][1]); }
 #pragma unroll
-                for (int e = 0; e < 6; ++e) d[e] = d[e] * ex[e];
+                for (int e = 0; e < 4; ++e) d[e] = d[e] * ex[e];
             }
         }
         if (a_bord) {
             const unsigned vm = pl ? a_vmp : a_vm;
 #pragma unroll
-            for (int e = 0; e < 12; ++e) d[e >> 1][e & 1] = (vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
+            for (int e = 0; e < 8; ++e) d[e >> 1][e & 1] = (vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
         }
         if (pl) {            // every other window column: the de-interleaved half of the scratch row
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 2; ++j)
                 *reinterpret_cast<f32x4 *>(xw + xoffp[PLANAR ? j : 0]) = f32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
         } else if (PLANAR) { // four consecutive columns into the de-interleaved row (one scratch format per instantiation)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 float *dst = xw + xoff[j];
                 dst[0] = d[2 * j][0]; dst[1] = d[2 * j + 1][0];
                 dst[20] = d[2 * j][1]; dst[21] = d[2 * j + 1][1];
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 2; ++j)
                 *reinterpret_cast<f32x4 *>(xw + xoff[j]) = f32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
         }
     };
@@ -308,14 +316,16 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     // input transform: the wave transforms the (tile, channel) pairs of its own scratch -- lane map 16 tiles x 2 k-steps x 2
     // channel parities, so that the 32 lanes of an LDS store group write a 64-float span of the [tile][k-step] image at most
     // 2-way conflicted (free)
-    const int w_t16 = lane & 15, w_kpl = (lane >> 4) & 1;
-    const float *const xr = xw + ((2 * w_kpl + lk) * 4) * XP + 2 * w_t16;
-    const int v_slot = (w_t16 & 1) * 16 + (w_t16 >> 1) * 2 + (swave & 1);           // MFMA lane of tile (row swave & 1, column w_t16)
-    const int v_lane = (cg >> 1) * VH_FLOATS + (lk * 32 + v_slot) * 4 + 2 * (cg & 1) + w_kpl;      // + xi * 256 (+ stage)
+    // (lane = tile column w_tx, tile row w_ty, channel lk of the wave's two: channel 2 w + lk of the chunk = k step w & 3, k
+    //  parity lk of sub-chunk w >> 2)
+    const int w_tx = lane & 15, w_ty = (lane >> 4) & 1;
+    const float *const xr = xw + (lk * 6 + 2 * w_ty) * XP + 2 * w_tx;
+    const int v_slot = (w_tx & 1) * 16 + (w_tx >> 1) * 2 + w_ty;                    // MFMA lane of tile (row w_ty, column w_tx)
+    const int v_lane = (swave >> 2) * VH_FLOATS + (lk * 32 + v_slot) * 4 + (swave & 3);      // + xi * 256 (+ stage)
     float patch[16];
     constexpr int pcol[4] = {0, PLANAR ? 2 : 1, PLANAR ? 1 : 2, 3};                  // register position of patch column c
     auto read_patch = [&]() __attribute__((always_inline)) {
-        const float *const xrp = xr - w_t16;                                        // column pairs (t16, t16 + 1) of both halves
+        const float *const xrp = xr - w_tx;                                         // column pairs (tx, tx + 1) of both halves
         if (PLANAR) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
