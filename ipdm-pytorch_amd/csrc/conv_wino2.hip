@@ -17,10 +17,10 @@
 //
 //   * one 512-thread workgroup per CU, tile = 32 Winograd tiles (4 x 32 pixels) x 128 couts; all EIGHT waves multiply:
 //     wave w owns positions 8 (w & 1) .. +7 of cout quarter (w >> 1) for all 32 tiles (8 accumulators of 32x32);
-//   * all eight waves stage: wave w the window rows of tile row (w & 1) for four channels (w >> 1) of each SIXTEEN-channel
-//     chunk (three 16-byte buffer loads per lane, GroupNorm+SiLU once per window element, wave-private LDS scratch), reads
-//     its (tile, channel) patches back and does B^T d B into the shared V stage: per MFMA half the staging instructions of
-//     the round-3 kernel, and none of them in a wave that only stages;
+//   * all eight waves stage: wave w all six window rows of channels 2 w, 2 w + 1 of each SIXTEEN-channel chunk (two 16-byte
+//     buffer loads per lane, GroupNorm+SiLU once per window element AND workgroup, wave-private LDS scratch), reads its
+//     (tile, channel) patches back -- 32 tiles x 2 channels -- and does B^T d B into the shared V stage: per MFMA a third of the
+//     staging instructions of the round-3 kernel, and none of them in a wave that only stages;
 //   * the U operands never touch LDS: a lane's four k steps of one position are 16 contiguous bytes of the packed image
 //     ([8-channel chunk][64-cout tile][xi][h][lk][cout 32][kp 4], unchanged), loaded from L2 straight into the MFMA's A
 //     registers half a chunk ahead, each position's registers reloaded in place right after its MFMAs: 32 registers;
