@@ -1182,11 +1182,12 @@ def test_smoke_pipeline_matches_oracle_psnr():
 def test_smoke_pipeline_fp64_arbiter():
     """Who is right when two float32 evaluations differ?  The reduced end-to-end pipeline once more on the CPU in FLOAT64
     (same float32 inputs, weights, draws and schedule constants: oracle.pipeline.progressive_slice on float64 tensors) is
-    the value both approximate.  Stage by stage -- every stored iterate of the projection loop, the FBP image, every
-    iterate of the image loops -- the HIP result may be at most 1.5x as far from it as the float32 CPU oracle is in rms (and
-    in max-abs up to the amplifying pass; 2x in max-abs after it).  One image-domain pass of these random-weight networks amplifies rounding ~100x (chaotically: the CPU
-    oracle's own distance to the arbiter moves 2.4x with nothing but its thread count, 1.2e-4 ... 2.8e-4), so "the
-    oracle's distance" is the worst of three thread counts; before that pass both sit at 1e-7 and the comparison is sharp."""
+    the value both approximate.  STAGE BY STAGE for the canonical seed -- every stored iterate of the projection loop, the FBP
+    image, every iterate of the image loops: up to the first amplifying pass both evaluations sit at 1e-7 of the arbiter and
+    the comparison is sharp (HIP at most 1.5x as far as the float32 CPU oracle, rms and max-abs).  One image-domain pass of
+    these random-weight networks then amplifies rounding ~100x, chaotically (round 3: the oracle's own distance moved 2.4x
+    with nothing but its thread count); after it this single sample only has to stay under the hard caps, and the criterion
+    is the median over seeds of test_smoke_pipeline_fp64_arbiter_over_seeds."""
     from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
     from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG, _RecordingNoise
     from ipdm_pytorch_amd.diffusion import NoiseSource
@@ -1220,7 +1221,8 @@ def test_smoke_pipeline_fp64_arbiter():
                                       torch.from_numpy(sino)[None, None].to(dt), lambda: next(it).to(dt), sharpen_num=70)
         return ([m.numpy() for m in mid["proj"]], mid["fbp"].numpy(), [m.numpy() for m in mid["img"]])
     m64 = oracle(torch.float64, 64)
-    m32 = [oracle(torch.float32, nt) for nt in (16, 32, 64)]
+    m32 = [oracle(torch.float32, nt) for nt in (32,)]      # (round 3 ran 16 / 32 / 64 threads here to show that the oracle's own distance
+                                                                # moves 2.4x with its thread count; the statistic over seeds replaced that)
     n_p, n_i = len(m64[0]), len(m64[2])
     hip = ([den.proj_denoise_result[k + 1] for k in range(n_p)], den.proj_denoise_convert2img_result[n_p],
            [den.progressive_denoise_result[k + 1] for k in range(n_i)])
@@ -1235,7 +1237,7 @@ def test_smoke_pipeline_fp64_arbiter():
         h = dist(pick(hip), pick(m64))
         cs = [dist(pick(m), pick(m64)) for m in m32]
         c = (max(x[0] for x in cs), max(x[1] for x in cs))
-        print("fp64 arbiter %-11s |hip-f64| max %.3e rms %.3e | |cpu32-f64| (16/32/64 threads) max %s rms %s | ratio max %.2f rms %.2f"
+        print("fp64 arbiter %-11s |hip-f64| max %.3e rms %.3e | |cpu32-f64| max %s rms %s | ratio max %.2f rms %.2f"
               % (name, h[0], h[1], ["%.2e" % x[0] for x in cs], ["%.2e" % x[1] for x in cs], h[0] / c[0], h[1] / c[1]))
         worst = max(worst, h[0] / c[0], h[1] / c[1])
         # Up to the amplifying pass (both evaluations at 1e-7 of the arbiter) the comparison is sharp: 1.5x in rms and max-abs.
@@ -1248,7 +1250,7 @@ def test_smoke_pipeline_fp64_arbiter():
         else:
             assert h[1] <= 1.5 * c[1] and h[0] <= 1.5 * c[0], (name, h, cs)
     # float32 vs float32 at the end of the chain: bounded by what the arbiter justifies (the sum of the two distances)
-    ff = dist(hip[2][-1], m32[1][2][-1])
+    ff = dist(hip[2][-1], m32[0][2][-1])
     scale = float(np.abs(m64[2][-1]).max())
     print("fp64 arbiter: worst stage ratio %.2f; |hip-cpu32(32 threads)| at the end max %.3e rms %.3e (scale %.3f)" % (worst, ff[0], ff[1], scale))
     assert ff[0] <= E2E_MAX_REL * max(1.0, scale)
