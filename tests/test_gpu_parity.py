@@ -301,6 +301,23 @@ def _conv_case_out(case, seed):
     return _conv_case(*case, seed=seed)
 
 
+# which kernel the cases that are meant to cover a specific one must land on (ipdm_conv_kernel_code; plain single-source shapes only)
+CONV_CASE_KERNELS = {
+    (8, 128, 0, 64, 96, 64, 96, 128, 3, 1, 2, True): 2,        # conv_wino2
+    (4, 128, 0, 200, 96, 200, 96, 128, 3, 1, 2, True): 2,
+    (2, 128, 0, 19, 250, 19, 250, 128, 3, 1, 2, True): 1,       # 32 of the 128-cout tiles: the 64-cout Winograd kernel
+    (2, 256, 0, 13, 125, 13, 125, 256, 3, 1, 2, True): 9,       # 16 direct tiles per sample: K slices inside conv_wino2
+    (1, 256, 0, 32, 32, 32, 32, 256, 3, 1, 2, True): 9,
+    (2, 64, 0, 32, 32, 32, 32, 64, 3, 1, 2, True): 4,           # 64 couts, few tiles: K-split direct kernel
+    (1, 256, 0, 8, 8, 8, 8, 768, 1, 1, 1, False): 4,
+    (2, 256, 0, 17, 57, 17, 57, 256, 1, 1, 0, True): 4,
+    (1, 8, 4, 33, 57, 33, 57, 8, 3, 1, 2, False): 5,            # (code of the same shape with ONE source)
+    (1, 64, 0, 70, 100, 70, 100, 1, 3, 1, 2, False): 5,
+    (2, 64, 0, 31, 45, 31, 45, 64, 3, 2, 0, False): 4,          # stride 2 to 16x23: conv_ws with a K split
+    (2, 64, 0, 37, 117, 19, 59, 128, 3, 2, 0, False): 4,
+}
+
+
 @pytest.mark.parametrize("case", [
     # B, C1, C2, Hs, Ws, H, W, Cout, ks, stride, act, res
     (1, 1, 0, 24, 40, 24, 40, 64, 3, 1, 0, False),          # stem
@@ -333,6 +350,11 @@ def _conv_case_out(case, seed):
     (2, 128, 64, 203, 90, 203, 90, 256, 3, 1, 2, False),    # two rounds with ragged rows (203), ragged width (90), concat, two cout tiles
 ])
 def test_conv_kernel(case):
+    if case in CONV_CASE_KERNELS:
+        from ipdm_pytorch_amd import _lib
+        B, C1, C2, Hs, Ws, H, W, Cout, ks, stride = case[:10]
+        got = _lib.lib().ipdm_conv_kernel_code(B, Cout, C1 + C2, ks, stride, H, W)
+        assert got == CONV_CASE_KERNELS[case], (case, got)
     _conv_case(*case, seed=200 + sum(case[:8]))
 
 
