@@ -41,7 +41,7 @@ int ipdm_abi_version(void);
  * (-1 | 0 | 1) ...; README.md lists them.  Every switch starts from the environment variable IPDM_<NAME> (read once, kept
  * as a debug alias) and changes only through this call afterwards.  Switches that shape packed weights or kernel choice
  * are recorded by ipdm_unet_create: a forward on a handle created under other values fails with IPDM_ERR_INVALID instead
- * of running on a mismatched layout; per-call switches (conv_no_up2, conv_no_wino, wino_split_min_tiles, conv1x1_no_quarter, conv_nm, direct_no_skip_fuse, gn_unfused,
+ * of running on a mismatched layout; per-call switches (conv_no_up2, conv_no_wino, conv_no_pw, wino_v1, wino2_min_tiles, conv1x1_no_quarter, conv_nm, direct_no_skip_fuse, gn_unfused,
  * gn_two_stage, unet_transpose, attn_no_zseq, conv_dbg, art_per_view: every weight form they choose between is packed, the workspace
  * need is re-queried per forward) may change under a live handle.  Returns IPDM_ERR_INVALID for an unknown name. */
 int ipdm_set_option(const char *name, int value);
@@ -282,6 +282,7 @@ int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
  *   5 = conv_direct (narrow layers, packed-f32 VALU)        6 = conv_nm (opt-in 16-cout MFMA)
  *   7 = parity form of an Upsample (never for this plain shape)   8 = conv_igemm (the generic 4-wave kernel)
  *   9 = conv_wino2 with K slices + combine pass (the layers with too few tiles per sample)
+ *   10 = conv_pw (wide 1x1 layers: the barrier-free pointwise kernel)
  *   102 | 103 = opt-in split-bf16;  -1 = bad argument.
  * Test aid (replaces nothing in the reference): a parity test asserts the kernel it believes it covers. */
 int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W);

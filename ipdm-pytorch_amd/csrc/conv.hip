@@ -374,7 +374,7 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
     // wide 3x3 convolutions (>80 % of the path's FLOPs) run on the persistent wave-specialised kernel (conv_ws.hip);
     // when their weights were packed for it (conv_weight_interleave); IPDM_CONV_LEGACY=1 at pack time keeps them here
     if (conv_sx_pieces(a.w_interleave)) return conv2d_sx_launch(a, st);
-    if (a.w_interleave) return conv2d_ws_launch(a, st);
+    if (a.w_interleave) return conv_pw_eligible(a) ? conv2d_pw_launch(a, st) : conv2d_ws_launch(a, st);      // (1x1: conv_pw.hip)
     if (!opt(OPT_CONV_NO_DIRECT) && conv_direct_eligible(a)) return conv2d_direct_launch(a, st);
     if (a.ksize == 3 && a.stride == 1) return wide ? launch_conv<3, 1, 2, 2, 8>(a, st) : launch_conv<3, 1, 1, 2, 8>(a, st);
     if (a.ksize == 3 && a.stride == 2) return wide ? launch_conv<3, 2, 2, 1, 8>(a, st) : launch_conv<3, 2, 1, 1, 8>(a, st);
@@ -388,6 +388,7 @@ int conv_kernel_code(const ConvArgs &a)
 {
     if (conv_sx_pieces(a.w_interleave)) return 100 + conv_sx_pieces(a.w_interleave);
     if (a.w_interleave) {
+        if (conv_pw_eligible(a)) return 10;
         if (conv_up2_eligible(a)) return 7;
         if (conv_wino_eligible(a)) {
             if (a.split_ws && conv_split(a) > 1) return 9;
@@ -403,14 +404,14 @@ int conv_kernel_code(const ConvArgs &a)
 int conv_stats_rows(const ConvArgs &a)
 {
     if (conv_sx_pieces(a.w_interleave)) return 0;                       // opt-in split-bf16 kernels: no fused statistics
-    if (a.w_interleave) return conv_ws_stats_rows(a);
+    if (a.w_interleave) return conv_pw_eligible(a) ? conv_pw_stats_rows(a) : conv_ws_stats_rows(a);
     if (!opt(OPT_CONV_NO_DIRECT) && conv_direct_eligible(a)) return conv_direct_stats_rows(a);
     return a.Ho * cdiv(a.Wo, 32);                                       // the 4-wave kernels below: a row per pixel row and tile column
 }
 
 int conv_split(const ConvArgs &a)
 {
-    if (conv_sx_pieces(a.w_interleave) || !a.w_interleave) return 1;
+    if (conv_sx_pieces(a.w_interleave) || !a.w_interleave || conv_pw_eligible(a)) return 1;
     if (conv_wino_eligible(a)) return conv_ws_split(a) > 1 ? conv_wino_split(a) : 1;      // (K slices inside conv_wino2)
     return conv_ws_split(a);
 }
@@ -453,6 +454,7 @@ bool conv_planar_ok(const ConvArgs &a)
 {
     if (a.upsample || (a.Hs & 1) || (a.Ws & 1)) return false;
     if (conv_sx_pieces(a.w_interleave)) return false;
+    if (a.w_interleave && conv_pw_eligible(a)) return true;            // (flat pixels: only the lane offsets differ)
     if (a.w_interleave) return conv_ws_planar_ok(a);                    // the wave-specialised kernels (conv_ws.hip)
     // (the stride-2 direct kernel and the 4-wave kernels below read NCHW only)
     return a.stride == 1 && !opt(OPT_CONV_NO_DIRECT) && !opt(OPT_DIRECT_NO_PLANAR) && conv_direct_eligible(a);

@@ -1,0 +1,329 @@
+// 1x1 convolutions (pointwise: qkv / proj_out of the AttentionBlocks, the channel-changing shortcuts of the ResidualBlocks;
+// Model/model.py:116-119,142-155) as a plain GEMM over channels on the exact-f32 MFMA of gfx950 -- round 4.
+//
+//     out[n][co][p] = sum_c W[co][c] * gn(x[n][c][p]) + bias[co] (+ res[n][co][p]),   p = the H*W pixels of a plane, FLAT
+//
+// Why a kernel of its own.  conv_ws.hip runs these layers through its producer/consumer structure (LDS stage, one hand-over
+// barrier per 32-channel chunk) at 0.4-0.6 of the f32 MFMA peak, and the first attempt at a pointwise kernel
+// (tools/experiments/conv_pw.hip: the conv_wino2 recipe, LDS-staged pixels, one barrier per chunk) did not beat it: what
+// those structures lose is the hand-over, not issue slots.  A pointwise operator needs no hand-over at
+// all -- both MFMA operands can be loaded from memory in exactly the lane layout the instruction wants:
+//
+//   * a WAVE is the unit of work, not a workgroup: item = 32 flat pixels x 128 couts (four 32x32 accumulators), walked over
+//     all input channels.  No LDS on the data path, NO BARRIER anywhere: the eight waves of a workgroup (one per CU, two per
+//     SIMD) never wait for each other, their phases drift apart, and whatever one wave does outside its MFMA stream (item
+//     epilogue, address arithmetic, a late load) is covered by the other wave of its SIMD;
+//   * operand roles swapped against conv_ws.hip -- pixels on M, couts on N -- so that four consecutive accumulator
+//     registers are four consecutive pixels of one cout (16-byte stores and residual loads, in-lane statistics);
+//   * A operand (pixels): lane (pixel l & 31, channel parity l >> 5) loads ONE dword x[c0 + 2 j + (l >> 5)][p0 + (l & 31)]: a
+//     wave-load is two runs of 128 contiguous bytes, addressing is a per-item lane offset plus a scalar channel offset;
+//   * B operand (weights): the slab conv_pack_weights already builds for these layers ([Cin][128-cout group][cout & 31][cout
+//     >> 5], interleave 4): the four floats a lane needs for the four cout blocks of one k step are adjacent -- one
+//     16-byte load (two runs of 512 contiguous bytes per wave-load), straight from L2 into the B registers;
+//   * both are loaded a whole 32-channel chunk (16 k steps) ahead into a register ring, reloaded in place right after the
+//     MFMAs that read them; the ring runs across item boundaries (the issue side is one chunk ahead of the multiplying side);
+//   * GroupNorm of the input (the qkv projection; no layer applies SiLU in front of a 1x1): one fma on the A register with
+//     the channel's {scale, shift} from a WAVE-PRIVATE table in LDS (rewritten when the wave's sample changes: no barrier);
+//   * parity-planar x1 (the output of an up2 convolution, conv_ws.hip): only the lane offsets differ.
+// Fused GroupNorm statistics of the output: one row of per-cout {sum, sum of squares} per 32 flat pixels.
+// Schedule: static, wave w of the launch takes items w, w + #waves, ...; items are ordered cout tile fastest, so the waves
+// of a CU that share a pixel tile read it from the same L1 / L2.
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+#include "unet_kernels.h"
+
+using namespace ipdm;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef IPDM_PW_KO
+#define IPDM_PW_KO 0                // compile-time timing knock-outs (tools/build_variants.sh; WRONG results): 1 no operand loads after
+#endif                              // the prologue, 4 no stores / residual / statistics
+
+namespace {
+
+constexpr int KC = 32;                                 // channels per chunk = depth of the register ring (16 k steps of 2)
+constexpr int DEPTH = KC / 2;
+constexpr int BN = 128;                                // couts per item
+constexpr int BP = 32;                                 // flat pixels per item
+constexpr int NW = 8;                                  // waves per workgroup
+constexpr int OOB = 0x7fffffff;
+
+__device__ inline float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ inline f32x4 bload4(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// The register ring is loaded and waited for BY HAND.  With builtin loads the compiler's wait-count pass cannot follow loads
+// that stay in flight across the loop's back edge: it drains the queue (s_waitcnt vmcnt(0)) at the top of every chunk, which
+// turns the ring into load-everything-then-multiply.  Invisible to that pass, the loads below are waited for with the exact
+// count: 2 (DEPTH - 1) ring loads are issued between a slot's pair and its use, loads return in order, and anything else the
+// wave has in flight by then (bias / residual loads, stores) is younger and only makes the wait stricter.  The compiler's
+// own waits (for ITS loads) do not know about the ring either and are likewise stricter than necessary, never weaker.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ inline i32x4 make_rsrc(const void *p, int bytes)
+{
+    const unsigned long long u = (unsigned long long)p;
+    return i32x4{(int)(unsigned)u, (int)((unsigned)(u >> 32) & 0xffffu), bytes, 0x00020000};
+}
+__device__ inline void ring_load(float &x, f32x4 &w, int x_v, i32x4 x_rsrc, int x_s, int w_v, i32x4 w_rsrc, int w_s)
+{
+    asm volatile("buffer_load_dword %0, %2, %3, %4 offen\n\t"
+                 "buffer_load_dwordx4 %1, %5, %6, %7 offen"
+                 : "=&v"(x), "=&v"(w) : "v"(x_v), "s"(x_rsrc), "s"(x_s), "v"(w_v), "s"(w_rsrc), "s"(w_s));
+}
+__device__ inline void ring_wait(float &x, f32x4 &w)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x), "+v"(w) : "n"(2 * (DEPTH - 1)));
+}
+
+struct Item { int n, p0, co0; };
+
+template <bool ACT, bool PLANAR>
+__global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 5, l31 = lane & 31;
+    // the workgroups of one XCD (blockIdx & 7) hold a contiguous run of wave indices: neighbouring items -- the cout tiles of
+    // one pixel tile, then the next pixel tile -- meet in the same L2
+    const int G = gridDim.x, per = G >> 3;
+    const int local = ((blockIdx.x & 7) * per + (blockIdx.x >> 3)) * NW + swave;
+    const int WT = G * NW;
+    if (local >= nitems) return;
+    const int n_my = (nitems - 1 - local) / WT + 1;
+    const int Ctot = a.C1 + a.C2, nch = Ctot / KC, HW = a.Ho * a.Wo;
+    const int plane_bytes = HW * 4;
+    auto decode = [&](int k) {
+        const int item = k * WT + local;
+        Item t;
+        t.co0 = (item % a.co_tiles) * BN;
+        const int rest = item / a.co_tiles;
+        t.p0 = (rest % a.tiles_x) * BP;
+        t.n = rest / a.tiles_x;
+        return t;
+    };
+
+    // ---------------------------------------------------------------- issue side: the chunk whose operands are being LOADED
+    Item nx = decode(0);
+    int i_ch = 0, i_k = 0;
+    int vx = 0, vxp = 0;                                   // the lane's byte offset inside a channel pair: NCHW / parity-planar x1
+    auto lane_offsets = [&]() __attribute__((always_inline)) {
+        const int p = nx.p0 + l31;
+        // (past the end of the plane -- the ragged last item -- the loads read the next channel or, past the tensor, 0: those
+        //  pixel ROWS of the accumulators are never stored, and a pixel's row depends on its own operand row only)
+        vx = (lk * HW + p) * 4;
+        if (PLANAR) {
+            const int pc = p < HW ? p : HW - 1;
+            const int y = pc / a.Wo, x = pc - y * a.Wo;
+            vxp = (lk * HW + ((y & 1) * 2 + (x & 1)) * (HW >> 2) + (y >> 1) * (a.Wo >> 1) + (x >> 1)) * 4;
+        }
+    };
+    const int wv = (lk * a.cout_pad + l31 * 4) * 4;        // the lane's byte offset inside a (channel pair, 128-cout group)
+    const i32x4 w_rsrc = make_rsrc(a.w, Ctot * a.cout_pad * 4);
+    float xs[DEPTH];
+    f32x4 ws[DEPTH];
+
+    // ---------------------------------------------------------------- multiplying side
+    f32x16 acc[4];
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float *const tab = lds + swave * (ACT ? Ctot * 2 : 0);                // the wave's {scale, shift} table
+    int tab_n = -1;
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
+    float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float one_k0 = lk == 0 ? 1.0f : 0.0f;
+    const int vo = (l31 * HW + 4 * lk) * 4;                // output / residual: cout l31 of a block, the lane's first pixel of a run of 8
+
+    // One chunk: the 16 k steps of the ring (4 MFMAs each); every slot is reloaded with the issue-side chunk's operands as
+    // soon as its MFMAs are out.
+    auto chunk = [&](int c_ch) __attribute__((always_inline)) {
+        const int c0 = i_ch * KC;
+        const bool from1 = c0 < a.C1;
+        const i32x4 x_rsrc = make_rsrc(from1 ? a.x1 + (size_t)nx.n * a.C1 * HW : a.x2 + (size_t)nx.n * a.C2 * HW, (from1 ? a.C1 : a.C2) * plane_bytes);
+        const int x_s = (from1 ? c0 : c0 - a.C1) * plane_bytes;
+        const int x_v = (PLANAR && from1) ? vxp : vx;
+        const int w_s = (c0 * a.cout_pad + nx.co0) * 4;
+        const float *const tc = tab + (c_ch * KC + lk) * 2;
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            ring_wait(xs[j], ws[j]);
+            float xv = xs[j];
+            if (ACT) {
+                const f32x2 st = *reinterpret_cast<const f32x2 *>(tc + j * 4);
+                xv = __builtin_fmaf(xv, st[0], st[1]);
+            }
+            const f32x4 wq = ws[j];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wq[b], acc[b], 0, 0, 0);
+            if (!(IPDM_PW_KO & 1)) ring_load(xs[j], ws[j], x_v, x_rsrc, x_s + j * 2 * plane_bytes, wv, w_rsrc, w_s + j * 2 * a.cout_pad * 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the issue side moves on: next chunk of its item, or the first chunk of the wave's next item (past the last item it
+        // keeps re-reading that item's chunks: valid addresses, results unused)
+        if (++i_ch == nch) {
+            i_ch = 0;
+            if (++i_k < n_my) { nx = decode(i_k); lane_offsets(); }
+        }
+    };
+
+    // ---------------------------------------------------------------- prologue: chunk 0 of item 0 in flight
+    lane_offsets();
+    Item cur = nx;
+    {
+        const i32x4 x_rsrc = make_rsrc(a.x1 + (size_t)nx.n * a.C1 * HW, a.C1 * plane_bytes);
+        const int x_v = PLANAR ? vxp : vx;
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) ring_load(xs[j], ws[j], x_v, x_rsrc, j * 2 * plane_bytes, wv, w_rsrc, (j * 2 * a.cout_pad + nx.co0) * 4);
+        i_ch = 1;
+    }
+
+    for (int k = 0; k < n_my; ++k) {
+        // ---------------------------------------------------------------- item start
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = zero16;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bv[b] = bload(b_rsrc, l31 * 4, (cur.co0 + 32 * b) * 4);
+        if (ACT && cur.n != tab_n) {
+            for (int c = lane; c < Ctot; c += 64)
+                *reinterpret_cast<f32x2 *>(tab + c * 2) = f32x2{a.gn_scale[(size_t)cur.n * Ctot + c], a.gn_shift[(size_t)cur.n * Ctot + c]};
+            tab_n = cur.n;
+        }
+        for (int c_ch = 0; c_ch < nch; ++c_ch) chunk(c_ch);
+
+        // ---------------------------------------------------------------- item epilogue
+        if (IPDM_PW_KO & 4) { cur = nx; continue; }
+        // + bias: one more k step with A = 1 (k lane 0), B = the cout's bias
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(one_k0, bv[b], acc[b], 0, 0, 0);
+        const size_t sample = (size_t)cur.n * a.Cout * HW;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * plane_bytes, 0x00020000);
+        // (no residual: zero records -- the loads return 0 and the add stays unconditional)
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0,
+                                                                                   a.res ? a.Cout * plane_bytes : 0, 0x00020000);
+        const int nv = HW - cur.p0;                        // valid pixels of the item (< 32: the ragged end of the plane)
+        const int row = cur.p0 / BP;
+        if (nv >= BP) {
+            // (a wait for a residual load also waits for every store issued before it: the loads run one cout block ahead of
+            //  the stores, and a layer without a residual issues none)
+            auto block = [&](int b, const f32x4 (&r)[4]) __attribute__((always_inline)) {
+                const int so = ((cur.co0 + 32 * b) * HW + cur.p0) * 4;
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = f32x4{acc[b][4 * q], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]} + r[q];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), o_rsrc, vo, so + q * 32, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 = __builtin_fmaf(v[e], v[e], s2); }
+                }
+                if (a.stats) {
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (lk == 0)
+                        *reinterpret_cast<f32x2 *>(a.stats + (((size_t)cur.n * a.stats_rows + row) * a.Cout + cur.co0 + 32 * b + l31) * 2) = f32x2{s1, s2};
+                }
+            };
+            if (a.res) {
+                f32x4 r[2][4];
+                auto fetch = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r[b & 1][q] = bload4(r_rsrc, vo, ((cur.co0 + 32 * b) * HW + cur.p0) * 4 + q * 32);
+                };
+                fetch(0);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (b + 1 < 4) fetch(b + 1);
+                    block(b, r[b & 1]);
+                }
+            } else {
+                const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                const f32x4 r0[4] = {z4, z4, z4, z4};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) block(b, r0);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int so = ((cur.co0 + 32 * b) * HW + cur.p0) * 4;
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int px = 8 * (i >> 2) + 4 * lk + (i & 3);
+                    const int off = px < nv ? vo + (i >> 2) * 32 + (i & 3) * 4 : OOB;
+                    const float v = acc[b][i] + bload(r_rsrc, off, so);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, off, so, 0);
+                    const float vm = px < nv ? v : 0.0f;
+                    s1 += vm; s2 = __builtin_fmaf(vm, vm, s2);
+                }
+                if (a.stats) {
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (lk == 0)
+                        *reinterpret_cast<f32x2 *>(a.stats + (((size_t)cur.n * a.stats_rows + row) * a.Cout + cur.co0 + 32 * b + l31) * 2) = f32x2{s1, s2};
+                }
+            }
+        }
+        cur = nx;
+    }
+}
+
+}  // namespace
+
+namespace ipdm {
+
+// The layers this kernel takes: every wide 1x1 with whole 128-cout groups and whole 32-channel chunks (all of the reference
+// architectures' qkv / proj_out / shortcut layers from 128 couts up), except the few low-resolution ones conv_ws.hip splits
+// along K (conv_ws_split: a rule of the layer alone, so the choice never depends on the batch).
+bool conv_pw_eligible(const ConvArgs &a)
+{
+    if (opt(OPT_CONV_NO_PW)) return false;
+    const int Ctot = a.C1 + a.C2;
+    if (a.ksize != 1 || a.stride != 1 || a.w_interleave != 4 || a.Cout % BN || a.cout_pad != a.Cout) return false;
+    if (a.upsample || a.H != a.Hs || a.W != a.Ws || a.Ho != a.H || a.Wo != a.W) return false;
+    if (Ctot % KC || Ctot < 2 * KC || (a.C2 && a.C1 % KC) || a.act == 2 || a.sk_w) return false;
+    if ((long)(a.C1 > a.C2 ? a.C1 : a.C2) * a.Ho * a.Wo >= (1L << 29) || (long)a.Cout * a.Ho * a.Wo >= (1L << 29)) return false;
+    return conv_ws_split(a) == 1;
+}
+
+int conv_pw_stats_rows(const ConvArgs &a) { return cdiv((long)a.Ho * a.Wo, BP); }
+
+int conv2d_pw_launch(const ConvArgs &args, hipStream_t st)
+{
+    ConvArgs a = args;
+    IPDM_REQUIRE(conv_pw_eligible(a), "conv2d_pw: not a layer of this kernel");
+    IPDM_REQUIRE(!a.x1_planar || (!(a.Ho & 1) && !(a.Wo & 1)), "conv2d_pw: parity-planar source of odd size %dx%d", a.Ho, a.Wo);
+    const int HW = a.Ho * a.Wo, Ctot = a.C1 + a.C2;
+    a.tiles_x = cdiv(HW, BP);
+    a.tiles_y = 1;
+    a.co_tiles = a.Cout / BN;
+    IPDM_REQUIRE(!a.stats || a.stats_rows == a.tiles_x, "conv2d_pw: statistics rows %d != %d", a.stats_rows, a.tiles_x);
+    const long nitems = (long)a.tiles_x * a.co_tiles * a.B;
+    IPDM_REQUIRE(nitems < (1L << 31), "conv2d_pw: too many items");
+    const int cus = device_cu_count();
+    long G = cdiv(nitems, NW) < cus ? cdiv(nitems, NW) : cus;
+    G = (G + 7) / 8 * 8;
+    const size_t lds_bytes = a.act ? (size_t)NW * Ctot * 2 * sizeof(float) : 0;
+    IPDM_REQUIRE(lds_bytes <= 64 * 1024, "conv2d_pw: %d input channels exceed the scale/shift tables", Ctot);
+    const bool prof = prof_enabled();
+    if (prof) prof_before(1, st);
+    if (a.act) {
+        if (a.x1_planar) hipLaunchKernelGGL((conv_pw_kernel<true, true>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
+        else hipLaunchKernelGGL((conv_pw_kernel<true, false>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
+    } else {
+        if (a.x1_planar) hipLaunchKernelGGL((conv_pw_kernel<false, true>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
+        else hipLaunchKernelGGL((conv_pw_kernel<false, false>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
+    }
+    if (prof) prof_after(1, 2.0 * a.B * HW * (double)a.Cout * Ctot, st);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
+
+}  // namespace ipdm

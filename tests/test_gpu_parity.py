@@ -315,6 +315,10 @@ CONV_CASE_KERNELS = {
     (1, 64, 0, 70, 100, 70, 100, 1, 3, 1, 2, False): 5,
     (2, 64, 0, 31, 45, 31, 45, 64, 3, 2, 0, False): 4,          # stride 2 to 16x23: conv_ws with a K split
     (2, 64, 0, 37, 117, 19, 59, 128, 3, 2, 0, False): 4,
+    (2, 256, 0, 57, 125, 57, 125, 768, 1, 1, 1, False): 10,    # conv_pw: the barrier-free pointwise kernel
+    (2, 256, 0, 40, 72, 40, 72, 256, 1, 1, 0, True): 10,
+    (2, 128, 128, 45, 95, 45, 95, 128, 1, 1, 0, False): 10,
+    (1, 64, 0, 64, 64, 64, 64, 128, 1, 1, 0, False): 10,
 }
 
 
@@ -348,6 +352,10 @@ CONV_CASE_KERNELS = {
     (2, 64, 0, 37, 117, 19, 59, 128, 3, 2, 0, False),       # stride 2 to 19x59
     (4, 128, 0, 200, 96, 200, 96, 128, 3, 1, 2, True),      # 300 tiles of 8x32x128: one full round of the persistent schedule + a 44-tile tail
     (2, 128, 64, 203, 90, 203, 90, 256, 3, 1, 2, False),    # two rounds with ragged rows (203), ragged width (90), concat, two cout tiles
+    (2, 256, 0, 57, 125, 57, 125, 768, 1, 1, 1, False),     # pointwise kernel: qkv with GroupNorm at the proj UNet's T = 7125 (ragged last item: 21 pixels)
+    (2, 256, 0, 40, 72, 40, 72, 256, 1, 1, 0, True),        # ... proj_out with its residual, whole items
+    (2, 128, 128, 45, 95, 45, 95, 128, 1, 1, 0, False),     # ... shortcut over a concat, ragged
+    (1, 64, 0, 64, 64, 64, 64, 128, 1, 1, 0, False),        # ... two 32-channel chunks (the ring's minimum)
 ])
 def test_conv_kernel(case):
     if case in CONV_CASE_KERNELS:
@@ -541,6 +549,8 @@ STATS_CHAIN_CASES = [
     (2, 16, 30, 44, 4, 1, 1, False, 1, 4),        # narrow 1x1
     (1, 48, 20, 24, 24, 3, 1, False, 2, 24),      # 16 < couts <= 32: the 4-wave kernel of conv.hip
     (2, 8, 37, 61, 8, 3, 2, False, 2, 8),         # narrow stride-2 (Downsample of the 4/8/16-channel levels): 4-wave kernel, ragged tiles
+    (2, 256, 40, 72, 256, 1, 1, True, 2, 64),     # pointwise kernel (conv_pw) as the producer: a statistics row per 32 flat pixels, residual
+    (3, 128, 37, 125, 128, 1, 1, False, 1, 64),   # ... ragged last item (4625 pixels), no residual
 ]
 
 
@@ -607,7 +617,11 @@ def test_conv_kernel_code_table():
         ((8, 128, 72, 3, 1, 228, 500), 1),       # Cin not a multiple of 16
         ((8, 256, 256, 3, 1, 32, 32), 9),        # K-split layer: K slices inside conv_wino2 + combine pass
         ((8, 320, 256, 3, 1, 32, 32), 4),        # ... whose couts are off the 128-cout tile: the K-split direct kernel
-        ((8, 768, 256, 1, 1, 64, 64), 3),        # qkv 1x1
+        ((8, 768, 256, 1, 1, 64, 64), 10),       # qkv 1x1: the pointwise kernel
+        ((8, 128, 256, 1, 1, 228, 500), 10),     # shortcut of the proj UNet's up path
+        ((1, 768, 256, 1, 1, 57, 125), 10),      # ... the choice is a rule of the layer: a lone slice takes the same kernel
+        ((8, 768, 256, 1, 1, 16, 16), 4),        # low resolution: conv_ws with its K split
+        ((8, 64, 128, 1, 1, 512, 512), 3),       # 64 couts: no whole 128-cout group
         ((8, 128, 128, 3, 2, 512, 512), 3),      # Downsample
         ((8, 8, 8, 3, 1, 2000, 912), 5),         # narrow level
         ((1, 24, 48, 3, 1, 20, 24), 8),          # 16 < Cout <= 32: the generic 4-wave kernel
@@ -618,6 +632,8 @@ def test_conv_kernel_code_table():
         assert code(8, 128, 128, 3, 1, 512, 512) == 1
     with _lib.option("conv_no_wino", 1):
         assert code(8, 128, 128, 3, 1, 512, 512) == 3
+    with _lib.option("conv_no_pw", 1):
+        assert code(8, 768, 256, 1, 1, 64, 64) == 3
     assert code(0, 128, 128, 3, 1, 8, 8) == -1
 
 
@@ -708,6 +724,71 @@ def test_wino2_run_to_run_determinism():
                  (1, 128, 16, 61, 129, 128, 1, True)]:
         bad += ws.stress(*case, reps=12)
     assert bad == 0
+
+
+PW_CASES = [
+    # B, C1, C2, H, W, Cout, act, res        (1x1; whole 128-cout groups, 32-channel chunks, not a K-split layer)
+    (2, 256, 0, 57, 125, 768, 1, False),     # qkv at T = 7125: six cout tiles per pixel tile, GroupNorm table, ragged last item
+    (2, 256, 0, 57, 125, 256, 0, True),      # proj_out + residual
+    (2, 128, 128, 45, 95, 128, 0, False),    # concat
+    (3, 96, 32, 41, 67, 128, 1, True),       # concat at a 96-channel boundary, GroupNorm over both sources, three samples
+    (1, 128, 0, 512, 512, 128, 0, True),     # several items per wave
+    (8, 256, 0, 64, 64, 768, 1, False),      # the img UNet's qkv at batch 8: the table is rewritten when a wave's sample changes
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_pointwise_kernel_bit_identical_to_the_staged_one(case):
+    """conv_pw.hip (a wave per 32 pixels x 128 couts, operands straight from memory, no barrier) accumulates every output
+    in the order conv_ws.hip's 1x1 path does -- channels ascending as an exact fmaf chain, + bias, + residual -- so the two
+    agree bit for bit, run after run; and both agree with torch (fp32) to 2e-5 relative."""
+    import torch.nn.functional as F
+    from ipdm_pytorch_amd import _lib
+    B, C1, C2, H, W, Cout, act, res = case
+    seed = 9100 + sum(case[:6])
+    x = torch.from_numpy(synth.hash_normal((B, C1, H, W), seed)) * 1.4 + 0.3
+    x2 = torch.from_numpy(synth.hash_normal((B, C2, H, W), seed + 1)) * 0.8 if C2 else None
+    w = torch.from_numpy(synth.hash_normal((Cout, C1 + C2, 1, 1), seed + 2)) / np.sqrt(C1 + C2)
+    b = torch.from_numpy(synth.hash_normal((Cout,), seed + 3))
+    gamma = torch.from_numpy(synth.hash_uniform((C1 + C2,), seed + 4)) + 0.5 if act else None
+    beta = torch.from_numpy(synth.hash_normal((C1 + C2,), seed + 5)) * 0.2 if act else None
+    r = torch.from_numpy(synth.hash_normal((B, Cout, H, W), seed + 6)) if res else None
+    code = _lib.lib().ipdm_conv_kernel_code
+    assert code(B, Cout, C1 + C2, 1, 1, H, W) == 10
+    got = _op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2)
+    for _ in range(3):
+        assert torch.equal(_op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2), got)
+    with _lib.option("conv_no_pw", 1):
+        assert code(B, Cout, C1 + C2, 1, 1, H, W) == 3
+        staged = _op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2)
+    assert torch.equal(got, staged)
+    h = x if x2 is None else torch.cat([x, x2], 1)
+    if act:
+        h = F.group_norm(h, ou.gn_groups(C1 + C2), gamma, beta, eps=1e-5)
+    want = F.conv2d(h, w, b)
+    if res:
+        want = want + r
+    assert (got.cpu() - want).abs().max() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_pointwise_kernel_statistics_and_planar_reader_equal_the_staged_kernel():
+    """The two chains the executor builds around a 1x1 layer -- producer of fused GroupNorm statistics, reader of a
+    parity-planar Upsample output -- give the same bits with either kernel behind the 1x1 layer."""
+    from ipdm_pytorch_amd import _lib
+    for case in STATS_CHAIN_CASES[-2:]:
+        mid, out, rows = _conv_gn_conv(case)
+        assert rows == -(-case[2] * case[3] // 32)          # a row per 32 flat pixels
+        with _lib.option("conv_no_pw", 1):
+            mid_s, out_s, rows_s = _conv_gn_conv(case)
+        assert rows_s == case[2] * -(-case[3] // 32)         # (conv_ws.hip: a row per pixel row and 32-pixel tile column)
+        assert torch.equal(mid, mid_s)
+        # (the statistics are sums over different pixel sets: the normalised result agrees to rounding, not bit for bit)
+        assert (out - out_s).abs().max() <= 2e-5 * max(1.0, out_s.abs().max().item())
+    for case in UP2_CASES[-2:]:
+        mid, out = _up_conv_chain(case)
+        with _lib.option("conv_no_pw", 1):
+            mid_s, out_s = _up_conv_chain(case)
+        assert torch.equal(mid, mid_s) and torch.equal(out, out_s)
 
 
 def test_direct_fallback_of_the_winograd_layers():
@@ -831,11 +912,12 @@ UP2_CASES = [
     (1, 128, 40, 72, 128, 64, 128, 3, 2),         # Winograd-domain reader of a parity-planar source, concatenated skip (80x144)
     (2, 64, 33, 47, 64, 0, 64, 3, 2),             # ... ragged tiles on both axes (66x94), border tiles on all sides
     (1, 64, 34, 50, 64, 64, 64, 3, 1),            # ... GroupNorm without SiLU, 68x100
+    (2, 128, 24, 40, 128, 128, 128, 1, 1),        # pointwise kernel reading cat(parity-planar, NCHW skip) with GroupNorm (48x80)
+    (1, 128, 27, 45, 128, 0, 256, 1, 0),          # ... a parity-planar source alone, ragged last item (54x90 = 4860 pixels)
 ]
 
 
-@pytest.mark.parametrize("case", UP2_CASES)
-def test_upsample_conv_parity_form(case):
+def _up_conv_chain(case):
     """Upsample (nearest 2x + 3x3 conv) evaluated as four 2x2-tap convolutions over the source grid (the taps that fall on
     one source pixel added up when the weights are packed; on narrow levels inside the direct kernel), its parity-planar output, the fused statistics of that output
     and every kind of reader (3x3 / 1x1 wave-specialised kernels with and without a concatenated skip, the narrow direct
@@ -876,6 +958,12 @@ def test_upsample_conv_parity_form(case):
     assert (d_mid.cpu() - mid).abs().max() <= 2e-5 * max(1.0, mid.abs().max().item())
     err = (d_out.cpu() - want).abs().max().item()
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
+    return d_mid.cpu(), d_out.cpu()
+
+
+@pytest.mark.parametrize("case", UP2_CASES)
+def test_upsample_conv_parity_form(case):
+    _up_conv_chain(case)
 
 
 def test_fused_statistics_equal_activation_pass():
