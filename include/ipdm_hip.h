@@ -31,7 +31,7 @@ extern "C" {
 #define IPDM_ERR_UNSUPPORTED (-4)
 
 const char *ipdm_last_error(void);
-/* ABI version of this header (bumped on any signature change): 2. */
+/* ABI version of this header (bumped on any signature change or new entry point): 3. */
 int ipdm_abi_version(void);
 
 /* Process-wide switches of the library (A/B experiments, opt-in evaluation modes); no reference counterpart -- the
@@ -41,7 +41,7 @@ int ipdm_abi_version(void);
  * (-1 | 0 | 1) ...; README.md lists them.  Every switch starts from the environment variable IPDM_<NAME> (read once, kept
  * as a debug alias) and changes only through this call afterwards.  Switches that shape packed weights or kernel choice
  * are recorded by ipdm_unet_create: a forward on a handle created under other values fails with IPDM_ERR_INVALID instead
- * of running on a mismatched layout; per-call switches (conv_no_up2, conv_no_wino, conv_no_pw, wino_v1, wino2_min_tiles, conv1x1_no_quarter, conv_nm, direct_no_skip_fuse, gn_unfused,
+ * of running on a mismatched layout; per-call switches (conv_no_up2, conv_no_wino, conv_no_pw, pw_item, wino_v1, wino2_min_tiles, conv1x1_no_quarter, conv_nm, direct_no_skip_fuse, gn_unfused,
  * gn_two_stage, unet_transpose, attn_no_zseq, conv_dbg, art_per_view: every weight form they choose between is packed, the workspace
  * need is re-queried per forward) may change under a live handle.  Returns IPDM_ERR_INVALID for an unknown name. */
 int ipdm_set_option(const char *name, int value);
@@ -265,6 +265,9 @@ int ipdm_art_project(ipdm_art_plan *plan, const float *d_volume, float *d_proj, 
  * overflow). */
 #define IPDM_PROF_CLASSES 6
 int ipdm_profile_begin(int32_t max_launches);
+/* ... recording only the classes whose bit is set in class_mask (an event pair costs the stream about a microsecond per
+ * launch: bench.py times its headline with the dominant kernel's classes only and the rest on an extra, untimed pass) */
+int ipdm_profile_begin_classes(int32_t max_launches, uint32_t class_mask);
 int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches, int32_t n_classes);
 
 /* kernel micro-benchmarks (tuning aid; allocate, fill with random data, time `iters` launches) */

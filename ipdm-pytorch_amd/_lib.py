@@ -31,7 +31,7 @@ class UnetCfg(C.Structure):
 _vp, _i32, _i64, _u64, _f32, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); restype int => status code checked by _call
-ABI_VERSION = 2          # ipdm_abi_version() of the header these prototypes were written against
+ABI_VERSION = 3          # ipdm_abi_version() of the header these prototypes were written against
 PROF_CLASSES = 6         # kernel classes of ipdm_profile_end (include/ipdm_hip.h)
 
 PROTOTYPES = {
@@ -81,6 +81,7 @@ PROTOTYPES = {
     "ipdm_op_up_conv_chain": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp,
                                         _i32, _i32, _vp, _vp, C.POINTER(_i32), _vp]),
     "ipdm_profile_begin": (C.c_int, [_i32]),
+    "ipdm_profile_begin_classes": (C.c_int, [_i32, C.c_uint32]),
     "ipdm_profile_end": (C.c_int, [C.POINTER(_f64 * PROF_CLASSES), C.POINTER(_f64 * PROF_CLASSES), C.POINTER(_i64 * PROF_CLASSES), _i32]),
     "ipdm_bench_conv2d": (C.c_int, [_i32] * 11 + [C.POINTER(_f32)]),
     "ipdm_bench_attention": (C.c_int, [_i32] * 5 + [C.POINTER(_f32)]),

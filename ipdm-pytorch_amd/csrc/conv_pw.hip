@@ -45,12 +45,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int KC = 32;                                 // channels per chunk = depth of the register ring (16 k steps of 2)
-constexpr int DEPTH = KC / 2;
 constexpr int BN = 128;                                // couts per item
-constexpr int BP = 32;                                 // flat pixels per item
 constexpr int NW = 8;                                  // waves per workgroup
 constexpr int OOB = 0x7fffffff;
+constexpr int KC_MIN = 32;                             // channel granularity the launcher asks for (both ring shapes divide it)
 
 __device__ inline float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
@@ -64,31 +62,41 @@ __device__ inline f32x4 bload4(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 // The register ring is loaded and waited for BY HAND.  With builtin loads the compiler's wait-count pass cannot follow loads
 // that stay in flight across the loop's back edge: it drains the queue (s_waitcnt vmcnt(0)) at the top of every chunk, which
 // turns the ring into load-everything-then-multiply.  Invisible to that pass, the loads below are waited for with the exact
-// count: 2 (DEPTH - 1) ring loads are issued between a slot's pair and its use, loads return in order, and anything else the
-// wave has in flight by then (bias / residual loads, stores) is younger and only makes the wait stricter.  The compiler's
-// own waits (for ITS loads) do not know about the ring either and are likewise stricter than necessary, never weaker.
+// count: (NPB + 1) (DEPTH - 1) ring loads are issued between a slot's loads and its use, loads return in order, and anything
+// else the wave has in flight by then (bias / residual loads, stores) is younger and only makes the wait stricter.  The
+// compiler's own waits (for ITS loads) do not know about the ring either and are likewise stricter than necessary, never
+// weaker.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ inline i32x4 make_rsrc(const void *p, int bytes)
 {
     const unsigned long long u = (unsigned long long)p;
     return i32x4{(int)(unsigned)u, (int)((unsigned)(u >> 32) & 0xffffu), bytes, 0x00020000};
 }
-__device__ inline void ring_load(float &x, f32x4 &w, int x_v, i32x4 x_rsrc, int x_s, int w_v, i32x4 w_rsrc, int w_s)
+__device__ inline void ring_load_x(float &x, int x_v, i32x4 x_rsrc, int x_s)
 {
-    asm volatile("buffer_load_dword %0, %2, %3, %4 offen\n\t"
-                 "buffer_load_dwordx4 %1, %5, %6, %7 offen"
-                 : "=&v"(x), "=&v"(w) : "v"(x_v), "s"(x_rsrc), "s"(x_s), "v"(w_v), "s"(w_rsrc), "s"(w_s));
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(x) : "v"(x_v), "s"(x_rsrc), "s"(x_s));
 }
-__device__ inline void ring_wait(float &x, f32x4 &w)
+__device__ inline void ring_load_w(f32x4 &w, int w_v, i32x4 w_rsrc, int w_s)
 {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x), "+v"(w) : "n"(2 * (DEPTH - 1)));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(w) : "v"(w_v), "s"(w_rsrc), "s"(w_s));
+}
+template <int N>
+__device__ inline void ring_wait(float &x0, float &x1, f32x4 &w)
+{
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(x0), "+v"(x1), "+v"(w) : "n"(N));
 }
 
 struct Item { int n, p0, co0; };
 
-template <bool ACT, bool PLANAR>
+// NPB: 32-pixel blocks per item (1: 32 x 128 outputs, a 16-step ring of 5 registers; 2: 64 x 128 outputs, an 8-step ring of 6
+// -- half the weight loads per MFMA, twice the work per item).  Both accumulate an output in the same order.
+template <bool ACT, bool PLANAR, int NPB>
 __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
 {
+    constexpr int DEPTH = 16 / NPB;                        // k steps in the ring
+    constexpr int KC = 2 * DEPTH;                          // channels per chunk
+    constexpr int BP = 32 * NPB;                           // flat pixels per item
+    constexpr int WAITN = (NPB + 1) * (DEPTH - 1);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,25 +123,28 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
     // ---------------------------------------------------------------- issue side: the chunk whose operands are being LOADED
     Item nx = decode(0);
     int i_ch = 0, i_k = 0;
-    int vx = 0, vxp = 0;                                   // the lane's byte offset inside a channel pair: NCHW / parity-planar x1
+    int vx[NPB], vxp[PLANAR ? NPB : 1];                    // the lane's byte offsets inside a channel pair: NCHW / parity-planar x1
     auto lane_offsets = [&]() __attribute__((always_inline)) {
-        const int p = nx.p0 + l31;
-        // (past the end of the plane -- the ragged last item -- the loads read the next channel or, past the tensor, 0: those
-        //  pixel ROWS of the accumulators are never stored, and a pixel's row depends on its own operand row only)
-        vx = (lk * HW + p) * 4;
-        if (PLANAR) {
-            const int pc = p < HW ? p : HW - 1;
-            const int y = pc / a.Wo, x = pc - y * a.Wo;
-            vxp = (lk * HW + ((y & 1) * 2 + (x & 1)) * (HW >> 2) + (y >> 1) * (a.Wo >> 1) + (x >> 1)) * 4;
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+            const int p = nx.p0 + 32 * pb + l31;
+            // (past the end of the plane -- the ragged last item -- the loads read the next channel or, past the tensor, 0:
+            //  those pixel ROWS of the accumulators are never stored, and a pixel's row depends on its own operand row only)
+            vx[pb] = (lk * HW + p) * 4;
+            if (PLANAR) {
+                const int pc = p < HW ? p : HW - 1;
+                const int y = pc / a.Wo, x = pc - y * a.Wo;
+                vxp[PLANAR ? pb : 0] = (lk * HW + ((y & 1) * 2 + (x & 1)) * (HW >> 2) + (y >> 1) * (a.Wo >> 1) + (x >> 1)) * 4;
+            }
         }
     };
     const int wv = (lk * a.cout_pad + l31 * 4) * 4;        // the lane's byte offset inside a (channel pair, 128-cout group)
     const i32x4 w_rsrc = make_rsrc(a.w, Ctot * a.cout_pad * 4);
-    float xs[DEPTH];
+    float xs[DEPTH][NPB];
     f32x4 ws[DEPTH];
 
     // ---------------------------------------------------------------- multiplying side
-    f32x16 acc[4];
+    f32x16 acc[NPB][4];
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float *const tab = lds + swave * (ACT ? Ctot * 2 : 0);                // the wave's {scale, shift} table
     int tab_n = -1;
@@ -142,29 +153,38 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
     const float one_k0 = lk == 0 ? 1.0f : 0.0f;
     const int vo = (l31 * HW + 4 * lk) * 4;                // output / residual: cout l31 of a block, the lane's first pixel of a run of 8
 
-    // One chunk: the 16 k steps of the ring (4 MFMAs each); every slot is reloaded with the issue-side chunk's operands as
+    // One chunk: the k steps of the ring (4 NPB MFMAs each); every slot is reloaded with the issue-side chunk's operands as
     // soon as its MFMAs are out.
     auto chunk = [&](int c_ch) __attribute__((always_inline)) {
         const int c0 = i_ch * KC;
         const bool from1 = c0 < a.C1;
         const i32x4 x_rsrc = make_rsrc(from1 ? a.x1 + (size_t)nx.n * a.C1 * HW : a.x2 + (size_t)nx.n * a.C2 * HW, (from1 ? a.C1 : a.C2) * plane_bytes);
         const int x_s = (from1 ? c0 : c0 - a.C1) * plane_bytes;
-        const int x_v = (PLANAR && from1) ? vxp : vx;
         const int w_s = (c0 * a.cout_pad + nx.co0) * 4;
         const float *const tc = tab + (c_ch * KC + lk) * 2;
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
-            ring_wait(xs[j], ws[j]);
-            float xv = xs[j];
+            ring_wait<WAITN>(xs[j][0], xs[j][NPB - 1], ws[j]);
+            float xv[NPB];
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) xv[pb] = xs[j][pb];
             if (ACT) {
                 const f32x2 st = *reinterpret_cast<const f32x2 *>(tc + j * 4);
-                xv = __builtin_fmaf(xv, st[0], st[1]);
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb) xv[pb] = __builtin_fmaf(xv[pb], st[0], st[1]);
             }
             const f32x4 wq = ws[j];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wq[b], acc[b], 0, 0, 0);
-            if (!(IPDM_PW_KO & 1)) ring_load(xs[j], ws[j], x_v, x_rsrc, x_s + j * 2 * plane_bytes, wv, w_rsrc, w_s + j * 2 * a.cout_pad * 4);
+            for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[pb], wq[b], acc[pb][b], 0, 0, 0);
+            if (!(IPDM_PW_KO & 1)) {
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb)
+                    ring_load_x(xs[j][pb], (PLANAR && from1) ? vxp[PLANAR ? pb : 0] : vx[pb], x_rsrc, x_s + j * 2 * plane_bytes);
+                ring_load_w(ws[j], wv, w_rsrc, w_s + j * 2 * a.cout_pad * 4);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // the issue side moves on: next chunk of its item, or the first chunk of the wave's next item (past the last item it
@@ -180,16 +200,21 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
     Item cur = nx;
     {
         const i32x4 x_rsrc = make_rsrc(a.x1 + (size_t)nx.n * a.C1 * HW, a.C1 * plane_bytes);
-        const int x_v = PLANAR ? vxp : vx;
 #pragma unroll
-        for (int j = 0; j < DEPTH; ++j) ring_load(xs[j], ws[j], x_v, x_rsrc, j * 2 * plane_bytes, wv, w_rsrc, (j * 2 * a.cout_pad + nx.co0) * 4);
+        for (int j = 0; j < DEPTH; ++j) {
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) ring_load_x(xs[j][pb], PLANAR ? vxp[PLANAR ? pb : 0] : vx[pb], x_rsrc, j * 2 * plane_bytes);
+            ring_load_w(ws[j], wv, w_rsrc, (j * 2 * a.cout_pad + nx.co0) * 4);
+        }
         i_ch = 1;
     }
 
     for (int k = 0; k < n_my; ++k) {
         // ---------------------------------------------------------------- item start
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[b] = zero16;
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[pb][b] = zero16;
 #pragma unroll
         for (int b = 0; b < 4; ++b) bv[b] = bload(b_rsrc, l31 * 4, (cur.co0 + 32 * b) * 4);
         if (ACT && cur.n != tab_n) {
@@ -203,71 +228,89 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
         if (IPDM_PW_KO & 4) { cur = nx; continue; }
         // + bias: one more k step with A = 1 (k lane 0), B = the cout's bias
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(one_k0, bv[b], acc[b], 0, 0, 0);
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[pb][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(one_k0, bv[b], acc[pb][b], 0, 0, 0);
         const size_t sample = (size_t)cur.n * a.Cout * HW;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * plane_bytes, 0x00020000);
         // (no residual: zero records -- the loads return 0 and the add stays unconditional)
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0,
                                                                                    a.res ? a.Cout * plane_bytes : 0, 0x00020000);
-        const int nv = HW - cur.p0;                        // valid pixels of the item (< 32: the ragged end of the plane)
-        const int row = cur.p0 / BP;
-        if (nv >= BP) {
-            // (a wait for a residual load also waits for every store issued before it: the loads run one cout block ahead of
-            //  the stores, and a layer without a residual issues none)
-            auto block = [&](int b, const f32x4 (&r)[4]) __attribute__((always_inline)) {
-                const int so = ((cur.co0 + 32 * b) * HW + cur.p0) * 4;
-                float s1 = 0.0f, s2 = 0.0f;
+        // a 32-pixel block x 32-cout block of the item: + residual, 16-byte stores, the block's statistics row
+        auto block = [&](int pb, int b, const f32x4 (&r)[4]) __attribute__((always_inline)) {
+            const int so = ((cur.co0 + 32 * b) * HW + cur.p0 + 32 * pb) * 4;
+            float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = f32x4{acc[b][4 * q], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]} + r[q];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), o_rsrc, vo, so + q * 32, 0);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = f32x4{acc[pb][b][4 * q], acc[pb][b][4 * q + 1], acc[pb][b][4 * q + 2], acc[pb][b][4 * q + 3]} + r[q];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), o_rsrc, vo, so + q * 32, 0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 = __builtin_fmaf(v[e], v[e], s2); }
-                }
-                if (a.stats) {
-                    s1 += __shfl_xor(s1, 32, 64);
-                    s2 += __shfl_xor(s2, 32, 64);
-                    if (lk == 0)
-                        *reinterpret_cast<f32x2 *>(a.stats + (((size_t)cur.n * a.stats_rows + row) * a.Cout + cur.co0 + 32 * b + l31) * 2) = f32x2{s1, s2};
-                }
-            };
+                for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 = __builtin_fmaf(v[e], v[e], s2); }
+            }
+            if (a.stats) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lk == 0)
+                    *reinterpret_cast<f32x2 *>(a.stats + (((size_t)cur.n * a.stats_rows + cur.p0 / 32 + pb) * a.Cout + cur.co0 + 32 * b + l31) * 2) = f32x2{s1, s2};
+            }
+        };
+        // ... of the ragged end of the plane (nv < 32 valid pixels): dword by dword
+        auto ragged_block = [&](int pb, int b, int nv) __attribute__((always_inline)) {
+            const int so = ((cur.co0 + 32 * b) * HW + cur.p0 + 32 * pb) * 4;
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int px = 8 * (i >> 2) + 4 * lk + (i & 3);
+                const int off = px < nv ? vo + (i >> 2) * 32 + (i & 3) * 4 : OOB;
+                const float v = acc[pb][b][i] + bload(r_rsrc, off, so);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, off, so, 0);
+                const float vm = px < nv ? v : 0.0f;
+                s1 += vm; s2 = __builtin_fmaf(vm, vm, s2);
+            }
+            if (a.stats) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lk == 0)
+                    *reinterpret_cast<f32x2 *>(a.stats + (((size_t)cur.n * a.stats_rows + cur.p0 / 32 + pb) * a.Cout + cur.co0 + 32 * b + l31) * 2) = f32x2{s1, s2};
+            }
+        };
+        if (HW - cur.p0 >= BP) {
+            // (a wait for a residual load also waits for every store issued before it: the loads run one block ahead of the
+            //  stores, and a layer without a residual issues none)
             if (a.res) {
                 f32x4 r[2][4];
-                auto fetch = [&](int b) __attribute__((always_inline)) {
+                auto fetch = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) r[b & 1][q] = bload4(r_rsrc, vo, ((cur.co0 + 32 * b) * HW + cur.p0) * 4 + q * 32);
+                    for (int q = 0; q < 4; ++q)
+                        r[t & 1][q] = bload4(r_rsrc, vo, ((cur.co0 + 32 * (t & 3)) * HW + cur.p0 + 32 * (t >> 2)) * 4 + q * 32);
                 };
                 fetch(0);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (b + 1 < 4) fetch(b + 1);
-                    block(b, r[b & 1]);
+                for (int t = 0; t < 4 * NPB; ++t) {
+                    if (t + 1 < 4 * NPB) fetch(t + 1);
+                    block(t >> 2, t & 3, r[t & 1]);
                 }
             } else {
                 const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
                 const f32x4 r0[4] = {z4, z4, z4, z4};
 #pragma unroll
-                for (int b = 0; b < 4; ++b) block(b, r0);
+                for (int t = 0; t < 4 * NPB; ++t) block(t >> 2, t & 3, r0);
             }
         } else {
+            for (int pb = 0; pb < NPB; ++pb) {
+                const int nv = HW - cur.p0 - 32 * pb;
+                if (nv <= 0) break;
+                if (nv >= 32) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int so = ((cur.co0 + 32 * b) * HW + cur.p0) * 4;
-                float s1 = 0.0f, s2 = 0.0f;
+                    for (int b = 0; b < 4; ++b) {
+                        f32x4 r[4];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int px = 8 * (i >> 2) + 4 * lk + (i & 3);
-                    const int off = px < nv ? vo + (i >> 2) * 32 + (i & 3) * 4 : OOB;
-                    const float v = acc[b][i] + bload(r_rsrc, off, so);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, off, so, 0);
-                    const float vm = px < nv ? v : 0.0f;
-                    s1 += vm; s2 = __builtin_fmaf(vm, vm, s2);
-                }
-                if (a.stats) {
-                    s1 += __shfl_xor(s1, 32, 64);
-                    s2 += __shfl_xor(s2, 32, 64);
-                    if (lk == 0)
-                        *reinterpret_cast<f32x2 *>(a.stats + (((size_t)cur.n * a.stats_rows + row) * a.Cout + cur.co0 + 32 * b + l31) * 2) = f32x2{s1, s2};
+                        for (int q = 0; q < 4; ++q) r[q] = bload4(r_rsrc, vo, ((cur.co0 + 32 * b) * HW + cur.p0 + 32 * pb) * 4 + q * 32);
+                        if (pb == 0) block(0, b, r); else block(NPB - 1, b, r);
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { if (pb == 0) ragged_block(0, b, nv); else ragged_block(NPB - 1, b, nv); }
                 }
             }
         }
@@ -288,12 +331,26 @@ bool conv_pw_eligible(const ConvArgs &a)
     const int Ctot = a.C1 + a.C2;
     if (a.ksize != 1 || a.stride != 1 || a.w_interleave != 4 || a.Cout % BN || a.cout_pad != a.Cout) return false;
     if (a.upsample || a.H != a.Hs || a.W != a.Ws || a.Ho != a.H || a.Wo != a.W) return false;
-    if (Ctot % KC || Ctot < 2 * KC || (a.C2 && a.C1 % KC) || a.act == 2 || a.sk_w) return false;
+    if (Ctot % KC_MIN || Ctot < 2 * KC_MIN || (a.C2 && a.C1 % KC_MIN) || a.act == 2 || a.sk_w) return false;
     if ((long)(a.C1 > a.C2 ? a.C1 : a.C2) * a.Ho * a.Wo >= (1L << 29) || (long)a.Cout * a.Ho * a.Wo >= (1L << 29)) return false;
     return conv_ws_split(a) == 1;
 }
 
-int conv_pw_stats_rows(const ConvArgs &a) { return cdiv((long)a.Ho * a.Wo, BP); }
+int conv_pw_stats_rows(const ConvArgs &a) { return cdiv((long)a.Ho * a.Wo, 32); }
+
+namespace {
+template <int NPB>
+void launch_pw(const ConvArgs &a, long G, size_t lds_bytes, long nitems, hipStream_t st)
+{
+    if (a.act) {
+        if (a.x1_planar) hipLaunchKernelGGL((conv_pw_kernel<true, true, NPB>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
+        else hipLaunchKernelGGL((conv_pw_kernel<true, false, NPB>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
+    } else {
+        if (a.x1_planar) hipLaunchKernelGGL((conv_pw_kernel<false, true, NPB>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
+        else hipLaunchKernelGGL((conv_pw_kernel<false, false, NPB>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
+    }
+}
+}  // namespace
 
 int conv2d_pw_launch(const ConvArgs &args, hipStream_t st)
 {
@@ -301,26 +358,28 @@ int conv2d_pw_launch(const ConvArgs &args, hipStream_t st)
     IPDM_REQUIRE(conv_pw_eligible(a), "conv2d_pw: not a layer of this kernel");
     IPDM_REQUIRE(!a.x1_planar || (!(a.Ho & 1) && !(a.Wo & 1)), "conv2d_pw: parity-planar source of odd size %dx%d", a.Ho, a.Wo);
     const int HW = a.Ho * a.Wo, Ctot = a.C1 + a.C2;
-    a.tiles_x = cdiv(HW, BP);
-    a.tiles_y = 1;
+    IPDM_REQUIRE(!a.stats || a.stats_rows == conv_pw_stats_rows(a), "conv2d_pw: statistics rows %d != %d", a.stats_rows, conv_pw_stats_rows(a));
+    const int cus = device_cu_count();
+    // Item shape: 64-pixel items load half the weights per MFMA and run ~7 % faster per pixel (tools/pw_check.py), but the
+    // static schedule's makespan is whole items per wave: take them when 2 x 0.93 x their rounds does not exceed the rounds of
+    // the 32-pixel items.  Both shapes produce the same bits, so the choice may look at the batch (pw_item: 1 / 2 force one).
     a.co_tiles = a.Cout / BN;
-    IPDM_REQUIRE(!a.stats || a.stats_rows == a.tiles_x, "conv2d_pw: statistics rows %d != %d", a.stats_rows, a.tiles_x);
+    const long waves = (long)cus * NW;
+    const long r32 = cdiv((long)cdiv(HW, 32) * a.co_tiles * a.B, waves), r64 = cdiv((long)cdiv(HW, 64) * a.co_tiles * a.B, waves);
+    const int forced = opt(OPT_PW_ITEM);
+    const int npb = forced ? forced : (1.86 * r64 <= (double)r32 ? 2 : 1);
+    a.tiles_x = cdiv(HW, 32 * npb);
+    a.tiles_y = 1;
     const long nitems = (long)a.tiles_x * a.co_tiles * a.B;
     IPDM_REQUIRE(nitems < (1L << 31), "conv2d_pw: too many items");
-    const int cus = device_cu_count();
     long G = cdiv(nitems, NW) < cus ? cdiv(nitems, NW) : cus;
     G = (G + 7) / 8 * 8;
     const size_t lds_bytes = a.act ? (size_t)NW * Ctot * 2 * sizeof(float) : 0;
     IPDM_REQUIRE(lds_bytes <= 64 * 1024, "conv2d_pw: %d input channels exceed the scale/shift tables", Ctot);
     const bool prof = prof_enabled();
     if (prof) prof_before(1, st);
-    if (a.act) {
-        if (a.x1_planar) hipLaunchKernelGGL((conv_pw_kernel<true, true>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
-        else hipLaunchKernelGGL((conv_pw_kernel<true, false>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
-    } else {
-        if (a.x1_planar) hipLaunchKernelGGL((conv_pw_kernel<false, true>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
-        else hipLaunchKernelGGL((conv_pw_kernel<false, false>), dim3((unsigned)G), dim3(512), lds_bytes, st, a, (int)nitems);
-    }
+    if (npb == 2) launch_pw<2>(a, G, lds_bytes, nitems, st);
+    else launch_pw<1>(a, G, lds_bytes, nitems, st);
     if (prof) prof_after(1, 2.0 * a.B * HW * (double)a.Cout * Ctot, st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;

@@ -11,19 +11,23 @@ struct Prof {
     bool on = false;
     std::vector<Rec> pool;
     size_t used = 0;
-    hipEvent_t pending = nullptr;
+    unsigned mask = ~0u;          // classes being recorded (ipdm_profile_begin_classes)
+    bool skip = false;            // the launch between prof_before / prof_after belongs to a class that is not
 } g_prof;
 }  // namespace
 
 bool prof_enabled() { return g_prof.on && g_prof.used < g_prof.pool.size(); }
 void prof_before(int cls, hipStream_t st)
 {
+    g_prof.skip = !(g_prof.mask >> cls & 1u);
+    if (g_prof.skip) return;
     Rec &r = g_prof.pool[g_prof.used];
     r.cls = cls;
     (void)hipEventRecord(r.a, st);
 }
 void prof_after(int cls, double flops, hipStream_t st)
 {
+    if (g_prof.skip) { g_prof.skip = false; return; }
     Rec &r = g_prof.pool[g_prof.used++];
     r.flops = flops;
     (void)hipEventRecord(r.b, st);
@@ -32,10 +36,14 @@ void prof_after(int cls, double flops, hipStream_t st)
 
 using namespace ipdm;
 
-// Starts recording up to max_launches kernel launches (events are created once and reused).
-extern "C" int ipdm_profile_begin(int32_t max_launches)
+// Starts recording up to max_launches kernel launches (events are created once and reused) of the classes in class_mask
+// (bit c = class c): an event pair costs the stream about a microsecond, so a timed region records only the classes it reports.
+extern "C" int ipdm_profile_begin(int32_t max_launches) { return ipdm_profile_begin_classes(max_launches, ~0u); }
+extern "C" int ipdm_profile_begin_classes(int32_t max_launches, uint32_t class_mask)
 {
     IPDM_REQUIRE(max_launches > 0, "profile_begin: bad capacity");
+    g_prof.mask = class_mask;
+    g_prof.skip = false;
     while ((int)g_prof.pool.size() < max_launches) {
         Rec r;
         IPDM_HIP_CHECK(hipEventCreate(&r.a));

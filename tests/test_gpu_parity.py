@@ -756,8 +756,9 @@ def test_pointwise_kernel_bit_identical_to_the_staged_one(case):
     code = _lib.lib().ipdm_conv_kernel_code
     assert code(B, Cout, C1 + C2, 1, 1, H, W) == 10
     got = _op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2)
-    for _ in range(3):
-        assert torch.equal(_op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2), got)
+    for rep in range(4):             # run after run, and with either item shape (32 / 64 pixels per wave)
+        with _lib.option("pw_item", 1 + rep % 2):
+            assert torch.equal(_op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2), got)
     with _lib.option("conv_no_pw", 1):
         assert code(B, Cout, C1 + C2, 1, 1, H, W) == 3
         staged = _op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2)
@@ -776,7 +777,11 @@ def test_pointwise_kernel_statistics_and_planar_reader_equal_the_staged_kernel()
     parity-planar Upsample output -- give the same bits with either kernel behind the 1x1 layer."""
     from ipdm_pytorch_amd import _lib
     for case in STATS_CHAIN_CASES[-2:]:
-        mid, out, rows = _conv_gn_conv(case)
+        with _lib.option("pw_item", 1):
+            mid1, out1, _ = _conv_gn_conv(case)
+        with _lib.option("pw_item", 2):
+            mid, out, rows = _conv_gn_conv(case)
+        assert torch.equal(mid, mid1) and torch.equal(out, out1)      # the statistics rows do not depend on the item shape
         assert rows == -(-case[2] * case[3] // 32)          # a row per 32 flat pixels
         with _lib.option("conv_no_pw", 1):
             mid_s, out_s, rows_s = _conv_gn_conv(case)
@@ -785,10 +790,52 @@ def test_pointwise_kernel_statistics_and_planar_reader_equal_the_staged_kernel()
         # (the statistics are sums over different pixel sets: the normalised result agrees to rounding, not bit for bit)
         assert (out - out_s).abs().max() <= 2e-5 * max(1.0, out_s.abs().max().item())
     for case in UP2_CASES[-2:]:
-        mid, out = _up_conv_chain(case)
         with _lib.option("conv_no_pw", 1):
             mid_s, out_s = _up_conv_chain(case)
-        assert torch.equal(mid, mid_s) and torch.equal(out, out_s)
+        for item in (1, 2):
+            with _lib.option("pw_item", item):
+                mid, out = _up_conv_chain(case)
+            assert torch.equal(mid, mid_s) and torch.equal(out, out_s)
+
+
+def test_profile_classes_mask():
+    """ipdm_profile_begin_classes records only the classes asked for (bench.py times its headline with the dominant kernel's
+    classes and the rest on an extra step): a pointwise launch is class 1, a wide 3x3 launch class 5 (Winograd, 128-cout
+    tiles); a too-short result array is refused."""
+    import ctypes as C
+    from ipdm_pytorch_amd import _lib
+    x = torch.from_numpy(synth.hash_normal((1, 128, 64, 64), 77))
+    w1 = torch.from_numpy(synth.hash_normal((128, 128, 1, 1), 78)) / 12
+    w3 = torch.from_numpy(synth.hash_normal((128, 128, 3, 3), 79)) / 34
+    b = torch.zeros(128)
+    NC = _lib.PROF_CLASSES
+
+    def run(mask):
+        fl, ms, nl = (C.c_double * NC)(), (C.c_double * NC)(), (C.c_int64 * NC)()
+        if mask is None:
+            _lib.call("ipdm_profile_begin", 64)
+        else:
+            _lib.call("ipdm_profile_begin_classes", 64, mask)
+        with _lib.option("wino2_min_tiles", 1):
+            _op_conv(x, w1, b, 1)
+            _op_conv(x, w3, b, 3)
+        torch.cuda.synchronize()
+        _lib.call("ipdm_profile_end", C.byref(fl), C.byref(ms), C.byref(nl), NC)
+        return list(nl), list(fl), list(ms)
+
+    nl, fl, ms = run(None)
+    assert nl[1] == 1 and nl[5] == 1 and sum(nl) == 2
+    assert fl[1] == 2.0 * 64 * 64 * 128 * 128 and fl[5] == 2.0 * 32 * 32 * 16 * 128 * 128 and ms[1] > 0 and ms[5] > 0
+    nl, _, _ = run(1 << 1)
+    assert nl[1] == 1 and sum(nl) == 1
+    nl, _, _ = run((1 << 5) | (1 << 3) | (1 << 0))
+    assert nl[5] == 1 and sum(nl) == 1
+    short = (C.c_double * 2)()
+    _lib.call("ipdm_profile_begin", 8)
+    with pytest.raises(RuntimeError):
+        _lib.call("ipdm_profile_end", C.byref(short), C.byref(short), C.byref((C.c_int64 * 2)()), 2)
+    fl, ms, nl = (C.c_double * NC)(), (C.c_double * NC)(), (C.c_int64 * NC)()
+    _lib.call("ipdm_profile_end", C.byref(fl), C.byref(ms), C.byref(nl), NC)
 
 
 def test_direct_fallback_of_the_winograd_layers():

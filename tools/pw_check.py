@@ -51,7 +51,8 @@ if mode in ("check", "all"):
         kc = code(B, Cout, C1 + C2, H, W)
         worst, nbad = 0.0, 0
         for rep in range(6):
-            got = op_conv(x, w, b, act, gamma, beta, r, x2)
+            with _lib.option("pw_item", 1 + rep % 2):      # both item shapes: the same bits
+                got = op_conv(x, w, b, act, gamma, beta, r, x2)
             d = (got - want).abs().max().item()
             worst = max(worst, d)
             nbad += int(not torch.isfinite(got).all().item())
@@ -70,16 +71,17 @@ BENCH = [  # B, C1, C2, H, W, Cout, ks, stride, act, res
 if mode in ("bench", "all"):
     ms = C.c_float()
     res = {}
-    for rnd in range(4):
+    ARMS = [("conv_no_pw", 0, "pw_item", 0), ("conv_no_pw", 1, "pw_item", 0), ("conv_no_pw", 0, "pw_item", 1), ("conv_no_pw", 0, "pw_item", 2)]
+    for rnd in range(8):
         for c in BENCH:
-            for k in range(2):
-                i = (k + rnd) % 2
-                with _lib.option("conv_no_pw", i):
+            for k in range(4):
+                i = (k + rnd) % 4
+                with _lib.option(ARMS[i][0], ARMS[i][1]), _lib.option(ARMS[i][2], ARMS[i][3]):
                     _lib.call("ipdm_bench_conv2d", *c, 10, C.byref(ms))
                 res.setdefault((c, i), []).append(ms.value)
     for c in BENCH:
         B, C1, C2, H, W, Co, ks, st, act, r = c
         fl = 2.0 * B * H * W * Co * (C1 + C2)
-        pw, ws = min(res[(c, 0)]), min(res[(c, 1)])
-        print("conv %-44s pw %.3f ms %6.1f TF/s (%.2f of peak) | ws %.3f ms %6.1f TF/s | pw/ws %.2f" %
-              (c, pw, fl / pw / 1e9, fl / pw / 1e9 / 157.3, ws, fl / ws / 1e9, pw / ws))
+        pw, ws, p32, p64 = (min(res[(c, i)]) for i in range(4))
+        print("conv %-44s pw %.3f ms %6.1f TF/s (%.2f of peak) | ws %.3f ms %6.1f TF/s | pw/ws %.2f | 32-pixel items %.2f  64-pixel items %.2f" %
+              (c, pw, fl / pw / 1e9, fl / pw / 1e9 / 157.3, ws, fl / ws / 1e9, pw / ws, p32 / ws, p64 / ws))
