@@ -830,11 +830,10 @@ def test_profile_classes_mask():
     assert nl[1] == 1 and sum(nl) == 1
     nl, _, _ = run((1 << 5) | (1 << 3) | (1 << 0))
     assert nl[5] == 1 and sum(nl) == 1
-    short = (C.c_double * 2)()
-    _lib.call("ipdm_profile_begin", 8)
-    with pytest.raises(RuntimeError):
-        _lib.call("ipdm_profile_end", C.byref(short), C.byref(short), C.byref((C.c_int64 * 2)()), 2)
     fl, ms, nl = (C.c_double * NC)(), (C.c_double * NC)(), (C.c_int64 * NC)()
+    _lib.call("ipdm_profile_begin", 8)
+    with pytest.raises(RuntimeError):          # the caller states its array length: one shorter than the class count is refused
+        _lib.call("ipdm_profile_end", C.byref(fl), C.byref(ms), C.byref(nl), NC - 1)
     _lib.call("ipdm_profile_end", C.byref(fl), C.byref(ms), C.byref(nl), NC)
 
 
