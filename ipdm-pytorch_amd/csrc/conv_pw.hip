@@ -80,10 +80,16 @@ __device__ inline void ring_load_w(f32x4 &w, int w_v, i32x4 w_rsrc, int w_s)
 {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(w) : "v"(w_v), "s"(w_rsrc), "s"(w_s));
 }
+// (the slot's registers are in / out operands of the wait: nothing that reads them can be scheduled above it)
 template <int N>
-__device__ inline void ring_wait(float &x0, float &x1, f32x4 &w)
+__device__ inline void ring_wait(float (&x)[1], f32x4 &w)
 {
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(x0), "+v"(x1), "+v"(w) : "n"(N));
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x[0]), "+v"(w) : "n"(N));
+}
+template <int N>
+__device__ inline void ring_wait(float (&x)[2], f32x4 &w)
+{
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(x[0]), "+v"(x[1]), "+v"(w) : "n"(N));
 }
 
 struct Item { int n, p0, co0; };
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
         const float *const tc = tab + (c_ch * KC + lk) * 2;
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
-            ring_wait<WAITN>(xs[j][0], xs[j][NPB - 1], ws[j]);
+            ring_wait<WAITN>(xs[j], ws[j]);
             float xv[NPB];
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb) xv[pb] = xs[j][pb];
