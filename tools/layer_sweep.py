@@ -75,12 +75,20 @@ for name, cfg, (H, W) in (("img", UNetConfig(), (512, 512)),
                 _, c1, c2, h, w, co, ks, st, act, res = k
                 if c2 and c1 % 8:       # the executor materialises such concats
                     c1, c2 = c1 + c2, 0
-                _lib.call("ipdm_bench_conv2d", B, c1, c2, h, w, co, ks, st, act, res, 5, C.byref(ms))
+                best = 1e30
+                for _ in range(2):          # (best of two calls: the first call of a shape pays allocation and clock ramp)
+                    _lib.call("ipdm_bench_conv2d", B, c1, c2, h, w, co, ks, st, act, res, 5, C.byref(ms))
+                    best = min(best, ms.value)
+                ms.value = best
                 ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
                 fl = 2.0 * B * ho * wo * co * (k[1] + k[2]) * ks * ks
             else:
                 _, heads, T = k
-                _lib.call("ipdm_bench_attention", B, heads, 64, T, 3, C.byref(ms))
+                best = 1e30
+                for _ in range(2):
+                    _lib.call("ipdm_bench_attention", B, heads, 64, T, 5, C.byref(ms))
+                    best = min(best, ms.value)
+                ms.value = best
                 fl = 4.0 * B * heads * T * T * 64
             cache[k] = (ms.value, fl)
         t, fl = cache[k]
