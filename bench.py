@@ -490,6 +490,7 @@ def main():
             line["speedup_vs_cpu_baseline"] = round(value * per_slice, 1)
         print(json.dumps(line))
     if torch.distributed.is_initialized():
+        idist.barrier()          # (rank 0 ran its untimed profiling step and printed the line: leave together)
         torch.distributed.destroy_process_group()
 
 
