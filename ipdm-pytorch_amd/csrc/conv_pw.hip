@@ -40,8 +40,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef IPDM_PW_KO
-#define IPDM_PW_KO 0                // compile-time timing knock-outs (tools/build_variants.sh; WRONG results): 1 no operand loads after
-#endif                              // the prologue, 4 no stores / residual / statistics
+#define IPDM_PW_KO 0                // compile-time timing knock-out (tools/build_variants.sh; WRONG results): 1 = no operand loads after the
+#endif                              // prologue.  (Skipping the epilogue is not a valid knock-out: the MFMAs become dead code.)
 
 namespace {
 
@@ -231,7 +231,6 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
         for (int c_ch = 0; c_ch < nch; ++c_ch) chunk(c_ch);
 
         // ---------------------------------------------------------------- item epilogue
-        if (IPDM_PW_KO & 4) { cur = nx; continue; }
         // + bias: one more k step with A = 1 (k lane 0), B = the cout's bias
 #pragma unroll
         for (int pb = 0; pb < NPB; ++pb)
