@@ -269,6 +269,11 @@ int ipdm_profile_begin(int32_t max_launches);
  * launch: bench.py times its headline with the dominant kernel's classes only and the rest on an extra, untimed pass) */
 int ipdm_profile_begin_classes(int32_t max_launches, uint32_t class_mask);
 int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_launches, int32_t n_classes);
+/* Diagnostic: one wave that samples the shader clock (s_memtime) and the 100 MHz reference (s_memrealtime) every period_us,
+ * `samples` times, into d_out[2 i], d_out[2 i + 1] (device memory).  On a stream of its own it co-resides with the kernels
+ * that fill the chip: the quotient of the differences is the clock the chip holds under them, with no profiler attached
+ * (tools/clock_probe.py). */
+int ipdm_clock_probe(uint64_t *d_out, int32_t samples, int32_t period_us, void *stream);
 
 /* kernel micro-benchmarks (tuning aid; allocate, fill with random data, time `iters` launches) */
 int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, int32_t W, int32_t Cout, int32_t ksize,

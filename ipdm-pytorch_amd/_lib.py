@@ -82,6 +82,7 @@ PROTOTYPES = {
                                         _i32, _i32, _vp, _vp, C.POINTER(_i32), _vp]),
     "ipdm_profile_begin": (C.c_int, [_i32]),
     "ipdm_profile_begin_classes": (C.c_int, [_i32, C.c_uint32]),
+    "ipdm_clock_probe": (C.c_int, [_vp, _i32, _i32, _vp]),
     "ipdm_profile_end": (C.c_int, [C.POINTER(_f64 * PROF_CLASSES), C.POINTER(_f64 * PROF_CLASSES), C.POINTER(_i64 * PROF_CLASSES), _i32]),
     "ipdm_bench_conv2d": (C.c_int, [_i32] * 11 + [C.POINTER(_f32)]),
     "ipdm_bench_attention": (C.c_int, [_i32] * 5 + [C.POINTER(_f32)]),

@@ -76,3 +76,32 @@ extern "C" int ipdm_profile_end(double *out_flops, double *out_ms, int64_t *out_
     g_prof.used = 0;
     return IPDM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- clock probe (diagnostic)
+// One wave that does nothing but read the two clocks: s_memtime (shader clock) and s_memrealtime (100 MHz reference) every
+// `period_us`, `samples` times.  Launched on a stream of its own it co-resides with whatever kernel fills the chip (one wave
+// slot, no LDS), so the quotient of the differences is the clock the chip HOLDS under that kernel -- with no profiler
+// attached and no stamp in the kernel being measured (MI355X_MICROARCH.md, DVFS give-back item 6).
+namespace {
+__global__ void clock_probe_kernel(unsigned long long *out, int samples, unsigned long long period_ticks)
+{
+    if (threadIdx.x != 0) return;
+    unsigned long long r_next = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < samples; ++i) {
+        unsigned long long r;
+        do { __builtin_amdgcn_s_sleep(32); r = __builtin_amdgcn_s_memrealtime(); } while (r < r_next);
+        out[2 * i] = __builtin_amdgcn_s_memtime();
+        out[2 * i + 1] = r;
+        r_next = r + period_ticks;
+    }
+}
+}  // namespace
+
+extern "C" int ipdm_clock_probe(uint64_t *d_out, int32_t samples, int32_t period_us, void *stream)
+{
+    IPDM_REQUIRE(d_out && samples > 1 && period_us > 0, "clock_probe: bad argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long *)d_out, samples,
+                       (unsigned long long)period_us * 100ull);
+    IPDM_LAUNCH_CHECK();
+    return IPDM_OK;
+}
