@@ -1,7 +1,9 @@
 """Effective clock and matrix-pipe occupancy per kernel from ONE rocprofv3 --pmc pass (GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES,
 --kernel-trace) over a reduced step:   python tools/clock_summary.py <results.db> <out.csv>
   clock    = sum GRBM_GUI_ACTIVE / 8 / sum duration        (the counter is summed over the 8 XCDs; MI355X_MICROARCH.md, DVFS give-back;
-                                                            reads high on dispatches shorter than ~0.3 ms)
+                                                            reads high on dispatches shorter than ~0.3 ms, and LOW by the
+                                                            10-16 % a profiled dispatch takes longer than an un-profiled one:
+                                                            not the clock the kernel runs at -- tools/clock_probe.py measures that)
   mfma_busy = sum SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x sum GRBM_GUI_ACTIVE / 8)"""
 import csv
 import sqlite3
