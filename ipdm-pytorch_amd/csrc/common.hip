@@ -33,7 +33,7 @@ const OptDef g_opt_def[OPT_COUNT] = {
     {"direct_no_s2", 0, false}, {"direct_no_skip_fuse", 0, true},
     {"conv_sx_cw2", 0, false}, {"conv_dbg", 0, true, 0, 0x3ff}, {"conv_vec4_strict", 0, false}, {"conv_no_splitk", 0, false},
     {"conv_no_wino", 0, true}, {"wino_v1", 0, true}, {"wino2_min_tiles", 192, true, 0, 1 << 24},
-    {"conv1x1_no_quarter", 0, true}, {"conv_no_pw", 0, true}, {"pw_item", 0, true, 0, 2}, {"conv_nm", 0, true, 0, 2},
+    {"conv1x1_no_quarter", 0, true}, {"conv_no_pw", 0, true}, {"pw_item", 0, true, 0, 2}, {"pw_force", 0, true}, {"conv_nm", 0, true, 0, 2},
     {"gn_two_stage", 0, true}, {"gn_unfused", 0, true},
     {"unet_transpose", -1, true, -1, 1},
     {"attn_no_kvsplit", 0, false}, {"attn_legacy", 0, false}, {"attn_no_zseq", 0, true},

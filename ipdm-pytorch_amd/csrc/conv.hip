@@ -404,14 +404,14 @@ int conv_kernel_code(const ConvArgs &a)
 int conv_stats_rows(const ConvArgs &a)
 {
     if (conv_sx_pieces(a.w_interleave)) return 0;                       // opt-in split-bf16 kernels: no fused statistics
-    if (a.w_interleave) return conv_pw_eligible(a) ? conv_pw_stats_rows(a) : conv_ws_stats_rows(a);
+    if (a.w_interleave) return conv_pw_stats_layer(a) ? conv_pw_stats_rows(a) : conv_ws_stats_rows(a);      // (asked for layers that want statistics)
     if (!opt(OPT_CONV_NO_DIRECT) && conv_direct_eligible(a)) return conv_direct_stats_rows(a);
     return a.Ho * cdiv(a.Wo, 32);                                       // the 4-wave kernels below: a row per pixel row and tile column
 }
 
 int conv_split(const ConvArgs &a)
 {
-    if (conv_sx_pieces(a.w_interleave) || !a.w_interleave || conv_pw_eligible(a)) return 1;
+    if (conv_sx_pieces(a.w_interleave) || !a.w_interleave || conv_pw_layer_ok(a)) return 1;      // (conv_pw's layers are never K-split ones)
     if (conv_wino_eligible(a)) return conv_ws_split(a) > 1 ? conv_wino_split(a) : 1;      // (K slices inside conv_wino2)
     return conv_ws_split(a);
 }
@@ -454,7 +454,7 @@ bool conv_planar_ok(const ConvArgs &a)
 {
     if (a.upsample || (a.Hs & 1) || (a.Ws & 1)) return false;
     if (conv_sx_pieces(a.w_interleave)) return false;
-    if (a.w_interleave && conv_pw_eligible(a)) return true;            // (flat pixels: only the lane offsets differ)
+    if (a.w_interleave && conv_pw_layer_ok(a)) return true;            // (either kernel such a layer can land on reads parity-planar x1)
     if (a.w_interleave) return conv_ws_planar_ok(a);                    // the wave-specialised kernels (conv_ws.hip)
     // (the stride-2 direct kernel and the 4-wave kernels below read NCHW only)
     return a.stride == 1 && !opt(OPT_CONV_NO_DIRECT) && !opt(OPT_DIRECT_NO_PLANAR) && conv_direct_eligible(a);

@@ -327,10 +327,10 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
 
 namespace ipdm {
 
-// The layers this kernel takes: every wide 1x1 with whole 128-cout groups and whole 32-channel chunks (all of the reference
+// The layers this kernel CAN take: every wide 1x1 with whole 128-cout groups and whole 32-channel chunks (all of the reference
 // architectures' qkv / proj_out / shortcut layers from 128 couts up), except the few low-resolution ones conv_ws.hip splits
-// along K (conv_ws_split: a rule of the layer alone, so the choice never depends on the batch).
-bool conv_pw_eligible(const ConvArgs &a)
+// along K (conv_ws_split: a rule of the layer alone).
+bool conv_pw_layer_ok(const ConvArgs &a)
 {
     if (opt(OPT_CONV_NO_PW)) return false;
     const int Ctot = a.C1 + a.C2;
@@ -339,6 +339,26 @@ bool conv_pw_eligible(const ConvArgs &a)
     if (Ctot % KC_MIN || Ctot < 2 * KC_MIN || (a.C2 && a.C1 % KC_MIN) || a.act == 2 || a.sk_w) return false;
     if ((long)(a.C1 > a.C2 ? a.C1 : a.C2) * a.Ho * a.Wo >= (1L << 29) || (long)a.Cout * a.Ho * a.Wo >= (1L << 29)) return false;
     return conv_ws_split(a) == 1;
+}
+
+// ... and the ones it DOES take.  An item is one wave walking all input channels: a launch with fewer items than waves runs
+// at the latency of that walk (27 us at 256 channels), where conv_ws.hip puts a whole workgroup on a quarter tile -- a lone
+// slice's qkv / proj_out launches were up to 2x slower here (profiles/r04d_layer_sweep_b1.txt).  Outputs are the same bits
+// either way, so a layer WITHOUT fused statistics chooses by the fill of THIS launch (>= 1.3 rounds of 32-pixel items);
+// the statistics rows of the two kernels differ in geometry (sums over different pixel sets round differently), so a layer
+// WITH fused statistics must not look at the batch: it comes here only if one sample alone brings >= 1024 items.
+bool conv_pw_stats_layer(const ConvArgs &a)
+{
+    if (!conv_pw_layer_ok(a)) return false;
+    return opt(OPT_PW_FORCE) || (long)cdiv((long)a.Ho * a.Wo, 32) * (a.Cout / BN) >= 1024;      // (pw_force: tests drive small shapes through the kernel)
+}
+bool conv_pw_eligible(const ConvArgs &a)
+{
+    if (!conv_pw_layer_ok(a)) return false;
+    if (a.stats) return conv_pw_stats_layer(a);
+    if (opt(OPT_PW_FORCE)) return true;
+    const long items = (long)cdiv((long)a.Ho * a.Wo, 32) * (a.Cout / BN) * a.B;
+    return 10 * items >= 13L * device_cu_count() * NW;
 }
 
 int conv_pw_stats_rows(const ConvArgs &a) { return cdiv((long)a.Ho * a.Wo, 32); }

@@ -136,7 +136,9 @@ void conv_pack_weights_up2(const float *w, int Cout, int Cin, int interleave, st
 // parity-planar [B*C][2][2][H/2][W/2] -> NCHW [B*C][H][W]
 int planar_to_linear_launch(const float *src, float *dst, long planes, int H, int W, hipStream_t st);
 int conv_ws_split(const ConvArgs &a);
-bool conv_pw_eligible(const ConvArgs &a);          // wide 1x1 layers: the barrier-free pointwise kernel (conv_pw.hip)
+bool conv_pw_eligible(const ConvArgs &a);          // wide 1x1 layers: the barrier-free pointwise kernel (conv_pw.hip) takes THIS launch
+bool conv_pw_layer_ok(const ConvArgs &a);          // ... could take the layer (shape rule)
+bool conv_pw_stats_layer(const ConvArgs &a);       // ... takes it when the layer leaves fused statistics (a rule of the layer alone)
 int conv_pw_stats_rows(const ConvArgs &a);
 int conv2d_pw_launch(const ConvArgs &a, hipStream_t st);
 int conv_direct_stats_rows(const ConvArgs &a);

@@ -358,12 +358,14 @@ CONV_CASE_KERNELS = {
     (1, 64, 0, 64, 64, 64, 64, 128, 1, 1, 0, False),        # ... two 32-channel chunks (the ring's minimum)
 ])
 def test_conv_kernel(case):
-    if case in CONV_CASE_KERNELS:
-        from ipdm_pytorch_amd import _lib
-        B, C1, C2, Hs, Ws, H, W, Cout, ks, stride = case[:10]
-        got = _lib.lib().ipdm_conv_kernel_code(B, Cout, C1 + C2, ks, stride, H, W)
-        assert got == CONV_CASE_KERNELS[case], (case, got)
-    _conv_case(*case, seed=200 + sum(case[:8]))
+    from ipdm_pytorch_amd import _lib
+    # (the pointwise kernel takes a launch by its fill -- these shapes are small: pw_force drives them through it)
+    with _lib.option("pw_force", 1 if CONV_CASE_KERNELS.get(case) == 10 else 0):
+        if case in CONV_CASE_KERNELS:
+            B, C1, C2, Hs, Ws, H, W, Cout, ks, stride = case[:10]
+            got = _lib.lib().ipdm_conv_kernel_code(B, Cout, C1 + C2, ks, stride, H, W)
+            assert got == CONV_CASE_KERNELS[case], (case, got)
+        _conv_case(*case, seed=200 + sum(case[:8]))
 
 
 def test_conv_kernel_random_shapes():
@@ -619,7 +621,8 @@ def test_conv_kernel_code_table():
         ((8, 320, 256, 3, 1, 32, 32), 4),        # ... whose couts are off the 128-cout tile: the K-split direct kernel
         ((8, 768, 256, 1, 1, 64, 64), 10),       # qkv 1x1: the pointwise kernel
         ((8, 128, 256, 1, 1, 228, 500), 10),     # shortcut of the proj UNet's up path
-        ((1, 768, 256, 1, 1, 57, 125), 10),      # ... the choice is a rule of the layer: a lone slice takes the same kernel
+        ((1, 768, 256, 1, 1, 57, 125), 3),       # ... a lone slice's launch would not fill the chip's waves: conv_ws (same bits)
+        ((1, 128, 256, 1, 1, 228, 500), 10),     # ... this one does
         ((8, 768, 256, 1, 1, 16, 16), 4),        # low resolution: conv_ws with its K split
         ((8, 64, 128, 1, 1, 512, 512), 3),       # 64 couts: no whole 128-cout group
         ((8, 128, 128, 3, 2, 512, 512), 3),      # Downsample
@@ -634,6 +637,8 @@ def test_conv_kernel_code_table():
         assert code(8, 128, 128, 3, 1, 512, 512) == 3
     with _lib.option("conv_no_pw", 1):
         assert code(8, 768, 256, 1, 1, 64, 64) == 3
+    with _lib.option("pw_force", 1):
+        assert code(1, 768, 256, 1, 1, 57, 125) == 10
     assert code(0, 128, 128, 3, 1, 8, 8) == -1
 
 
@@ -754,11 +759,12 @@ def test_pointwise_kernel_bit_identical_to_the_staged_one(case):
     beta = torch.from_numpy(synth.hash_normal((C1 + C2,), seed + 5)) * 0.2 if act else None
     r = torch.from_numpy(synth.hash_normal((B, Cout, H, W), seed + 6)) if res else None
     code = _lib.lib().ipdm_conv_kernel_code
-    assert code(B, Cout, C1 + C2, 1, 1, H, W) == 10
-    got = _op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2)
-    for rep in range(4):             # run after run, and with either item shape (32 / 64 pixels per wave)
-        with _lib.option("pw_item", 1 + rep % 2):
-            assert torch.equal(_op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2), got)
+    with _lib.option("pw_force", 1):     # (the test shapes are small: by its fill rule the kernel would leave some of them to conv_ws)
+        assert code(B, Cout, C1 + C2, 1, 1, H, W) == 10
+        got = _op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2)
+        for rep in range(4):             # run after run, and with either item shape (32 / 64 pixels per wave)
+            with _lib.option("pw_item", 1 + rep % 2):
+                assert torch.equal(_op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2), got)
     with _lib.option("conv_no_pw", 1):
         assert code(B, Cout, C1 + C2, 1, 1, H, W) == 3
         staged = _op_conv(x, w, b, 1, act=act, gamma=gamma, beta=beta, res=r, x2=x2)
@@ -775,6 +781,15 @@ def test_pointwise_kernel_bit_identical_to_the_staged_one(case):
 def test_pointwise_kernel_statistics_and_planar_reader_equal_the_staged_kernel():
     """The two chains the executor builds around a 1x1 layer -- producer of fused GroupNorm statistics, reader of a
     parity-planar Upsample output -- give the same bits with either kernel behind the 1x1 layer."""
+    from ipdm_pytorch_amd import _lib
+    _lib.set_option("pw_force", 1)
+    try:
+        _pw_chains()
+    finally:
+        _lib.set_option("pw_force", 0)
+
+
+def _pw_chains():
     from ipdm_pytorch_amd import _lib
     for case in STATS_CHAIN_CASES[-2:]:
         with _lib.option("pw_item", 1):
