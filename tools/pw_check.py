@@ -48,10 +48,11 @@ if mode in ("check", "all"):
         with _lib.option("conv_no_pw", 1):
             kc_ws = code(B, Cout, C1 + C2, H, W)
             want = op_conv(x, w, b, act, gamma, beta, r, x2)
-        kc = code(B, Cout, C1 + C2, H, W)
+        with _lib.option("pw_force", 1):
+            kc = code(B, Cout, C1 + C2, H, W)
         worst, nbad = 0.0, 0
         for rep in range(6):
-            with _lib.option("pw_item", 1 + rep % 2):      # both item shapes: the same bits
+            with _lib.option("pw_item", 1 + rep % 2), _lib.option("pw_force", 1):      # (small shapes: past the launcher's fill rule)      # both item shapes: the same bits
                 got = op_conv(x, w, b, act, gamma, beta, r, x2)
             d = (got - want).abs().max().item()
             worst = max(worst, d)
@@ -71,17 +72,17 @@ BENCH = [  # B, C1, C2, H, W, Cout, ks, stride, act, res
 if mode in ("bench", "all"):
     ms = C.c_float()
     res = {}
-    ARMS = [("conv_no_pw", 0, "pw_item", 0), ("conv_no_pw", 1, "pw_item", 0), ("conv_no_pw", 0, "pw_item", 1), ("conv_no_pw", 0, "pw_item", 2)]
+    ARMS = [("conv_no_pw", 0, "pw_item", 0, 0), ("conv_no_pw", 1, "pw_item", 0, 0), ("conv_no_pw", 0, "pw_item", 1, 1), ("conv_no_pw", 0, "pw_item", 2, 1)]      # (the forced item shapes also force the kernel)
     for rnd in range(8):
         for c in BENCH:
             for k in range(4):
                 i = (k + rnd) % 4
-                with _lib.option(ARMS[i][0], ARMS[i][1]), _lib.option(ARMS[i][2], ARMS[i][3]):
+                with _lib.option(ARMS[i][0], ARMS[i][1]), _lib.option(ARMS[i][2], ARMS[i][3]), _lib.option("pw_force", ARMS[i][4]):
                     _lib.call("ipdm_bench_conv2d", *c, 10, C.byref(ms))
                 res.setdefault((c, i), []).append(ms.value)
     for c in BENCH:
         B, C1, C2, H, W, Co, ks, st, act, r = c
         fl = 2.0 * B * H * W * Co * (C1 + C2)
         pw, ws, p32, p64 = (min(res[(c, i)]) for i in range(4))
-        print("conv %-44s pw %.3f ms %6.1f TF/s (%.2f of peak) | ws %.3f ms %6.1f TF/s | pw/ws %.2f | 32-pixel items %.2f  64-pixel items %.2f" %
+        print("conv %-44s default %.3f ms %6.1f TF/s (%.2f of peak) | ws %.3f ms %6.1f TF/s | pw/ws %.2f | 32-pixel items %.2f  64-pixel items %.2f" %
               (c, pw, fl / pw / 1e9, fl / pw / 1e9 / 157.3, ws, fl / ws / 1e9, pw / ws, p32 / ws, p64 / ws))
