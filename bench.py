@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- CT slices/s of the full dual-domain partial-diffusion sample on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N>1: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set: the driver's form) this process IS a rank; a bare
+`python bench.py --gpus N` starts its own ranks -- the parent, before it has imported anything that touches the GPU, runs
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same
+args>` as a fresh CHILD process (never an exec), relays rank 0's JSON line and exits with the child's return code.
 
 One "step" = one pass of the hot path over one batch of synthetic 0.25-dose slices per GPU:
 proj-domain guided reverse process (t_start_proj=[15,15,15], adaptive guidance, 45 UNet forwards at
@@ -112,6 +117,26 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child job and relay its line.  Nothing in this
+    process has touched the GPU (no torch import yet), and the job is a child process, not an exec of this one."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in proc.stdout:                                  # rank 0's ONE JSON line to stdout, anything else to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def make_inputs(batch, slice_id0, device, geometry=None):
     """Synthetic 0.25-dose sinograms of ellipse phantoms, keyed by global slice id; `geometry`: FBP
     geometry keywords (fbp.ALT_GEOMETRY for the 1152 x 736 shape), default = the reference geometry."""
@@ -185,6 +210,8 @@ def cpu_baseline():
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     import torch
     import ipdm_pytorch_amd
     from ipdm_pytorch_amd import _lib, dist as idist
@@ -193,7 +220,7 @@ def main():
 
     rank, world, local = idist.init_from_env()
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's --nproc-per-node must equal --gpus" % (args.gpus, world))
     # one rank per GPU; IPDM_BENCH_SHARE_GPU=1 (plumbing test on a 1-GPU box) puts every rank on device 0
     dev_index = 0 if os.environ.get("IPDM_BENCH_SHARE_GPU") else local
     device = "cuda:%d" % dev_index
@@ -226,20 +253,25 @@ def main():
         return den._img_dense(x, None, False)[-1]
     ldct = ldct_images() if img_only else None
 
-    own_done = [0.0]
+    # per rank and step: the time of its OWN slices -- an event pair around local_step() on the launch stream, no host
+    # synchronisation inside the timed region (the all-gather that follows makes everybody wait for the slowest rank; the
+    # record shows the imbalance itself, not only its effect)
+    own_ev = []
 
     def local_step():
         if img_only:
             return img_only_step(ldct)
         return den.proj_denoiser_device()[0] if alt else den.progressive_denoiser_device(sharpen_num=70)
 
-    def step():
-        out = local_step()
-        if world > 1:
-            # this rank's own finish time, BEFORE the all-gather makes everybody wait for the slowest rank (reported per
-            # rank beside the max: a scaling record then shows imbalance, not just its effect)
-            torch.cuda.synchronize()
-            own_done[0] = time.perf_counter()
+    def step(timed=False):
+        if timed and world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = local_step()
+            e1.record()
+            own_ev.append((e0, e1))
+        else:
+            out = local_step()
         return idist.all_gather_slices(out, n_global, rank, world)
 
     for _ in range(args.warmup):
@@ -258,14 +290,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         draw0 = den._noise().draw          # first draw index of the last timed step (alt-mode comparison below)
-        out = step()
+        out = step(timed=True)
     draws_per_step = den._noise().draw - draw0
     torch.cuda.synchronize()
     idist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    # per rank: the time at which its own slices of the LAST step were finished (steps before it end in the all-gather)
-    own_ms = idist.gather_over_ranks(((own_done[0] - t0) if world > 1 else elapsed) / args.steps * 1e3, device)
+    # per rank: the mean over the timed steps of its own work (event pairs around local_step(), the all-gather excluded)
+    own_mean = (sum(a.elapsed_time(b) for a, b in own_ev) / len(own_ev)) if own_ev else elapsed / args.steps * 1e3
+    own_ms = idist.gather_over_ranks(own_mean, device)
     elapsed = idist.max_over_ranks(elapsed, device)
     roofline = None
     extra = {}
@@ -306,8 +339,9 @@ def main():
                 extra[name] = {"tflops": round(fl[c] / (ms[c] * 1e-3) / 1e12, 2), "ms_total": round(ms[c], 2),
                                "launches": int(nl[c])}
         extra["dominant_kernel_time_share"] = round(ms[dom] * 1e-3 / elapsed, 4) if nl[dom] else None
-        extra["note"] = ("the dominant kernel's classes are event-timed inside the timed region; the other classes on one extra "
-                         "untimed step, scaled to %d step(s)" % args.steps)
+        extra["note"] = ("the dominant kernel's classes are event-timed inside the timed region; the other classes on ONE extra "
+                         "untimed step of rank 0 (the other ranks wait at the final barrier), their ms_total / launches scaled to "
+                         "%d step(s)" % args.steps)
         if nl[4]:
             # the bandwidth-bound kernel family: narrow direct convolutions (4/8/16 channels at 2000x912 / 1000x456)
             gbs = fl[4] / (ms[4] * 1e-3) / 1e9
@@ -335,7 +369,7 @@ def main():
                        "rccl_ranks": idist.describe(),
                        "per_rank_ms_per_step": {"min": round(min(own_ms), 2), "max": round(max(own_ms), 2),
                                                 "all": [round(v, 2) for v in own_ms],
-                                                "note": "each rank's own slices finished (before the all-gather)"},
+                                                "note": "each rank's own work per step (HIP events around its slices, the all-gather excluded), mean over the timed steps"},
                        "weights": "random-init reference architectures (29.1M img / 28.4M proj params)",
                        "work_per_slice": "85.1 TFLOP as the reference evaluates it.  Executed here: the Upsample layers (nearest 2x + "
                                          "3x3 conv) as four 2x2-tap parity convolutions over pre-added weights (4 of 9 multiply-adds per "
