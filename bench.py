@@ -28,7 +28,6 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32-input MFMA peak (= f32 vector peak)
 PEAK_HBM_GBS = 8000.0             # same guide: HBM3E peak (6.3 TB/s achievable by a streaming copy)
-PEAK_BF16_MFMA_TFLOPS = 2516.8    # same table: the dense bf16 MFMA rate is 16x the f32 one
 
 
 def kernel_source_sha16(fname="conv_wino.hip"):
@@ -39,7 +38,7 @@ def kernel_source_sha16(fname="conv_wino.hip"):
 
 
 def conv_mode():
-    return {"3": "split-bf16-x6", "2": "split-bf16-x3"}.get(os.environ.get("IPDM_CONV_SPLIT", ""), "exact-f32")
+    return "exact-f32"
 
 
 def measured_traffic(cls=5):
@@ -75,14 +74,7 @@ def cpu_model():
 
 
 def dominant_kernel(cls=5):
-    """Name and MFMA roofline of the wide 3x3 stride-1 convolution in the mode this process runs in.
-    Default: exact-f32 MFMA.  IPDM_CONV_SPLIT=3|2 (opt-in): each f32 operand is split into 3|2 bf16 pieces and one
-    algorithmic MAC costs 6|3 bf16 MFMA MACs, so the roofline of that algorithm is the dense bf16 peak / 6|3."""
-    split = os.environ.get("IPDM_CONV_SPLIT", "")
-    if split in ("2", "3"):
-        terms = 6 if split == "3" else 3
-        return ("conv_sx_kernel<WM,%s> (3x3 stride-1 implicit GEMM, persistent wave-specialised, %s-piece split-bf16 = "
-                "%d bf16 MFMA terms per f32 product, f32 accumulate)" % (split, split, terms), PEAK_BF16_MFMA_TFLOPS / terms)
+    """Name and MFMA roofline of the wide 3x3 stride-1 convolutions' kernel (exact-f32 MFMA)."""
     if cls == 5:
         return ("conv_wino2_kernel (wide 3x3 stride-1 convolutions with whole 128-cout tiles in the Winograd F(2x2,3x3) domain: "
                 "persistent, 8 waves that stage AND multiply, U operands L2 -> registers, exact-f32 MFMA; achieved counts the "
@@ -106,7 +98,7 @@ def parse():
     ap.add_argument("--no-ultra", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 leg (N=1 only)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the reference-form Upsample leg (N=1 only)")
     ap.add_argument("--shape", choices=["ref", "alt", "img"], default="ref",
                     help="ref: the headline (reference geometry 2000x912, full dual-domain sample).  alt: run the TIMED loop on "
                          "BASELINE config C3's literal shape instead (B x 1152 views x 736 detectors, proj UNet + HIP FBP only) "
@@ -206,6 +198,60 @@ def cpu_baseline():
     of.convert(geo, sino)
     out["fbp"] = time.perf_counter() - t0
     return out, max(used.values()), cores
+
+
+def cpu_baseline_host(per_proc_threads, n_fwd_proj, n_fwd_img, budget_s=150.0):
+    """The host-filling figure: the reference's own loop is one slice at a time
+    (Utils/train_test_utils.py:290-294), so the fair 'same box's host cores' number is P independent oracle processes on
+    disjoint core sets, P = physical cores // threads.  Each child times ONE img-UNet forward @512x512 (and, if the budget
+    allows, one proj forward @2000x912) with all P running at once; per-slice time by the same call counts; value = P / that."""
+    import subprocess
+    try:
+        phys = len({(l.split()[0], l.split()[1]) for l in subprocess.run(["lscpu", "-p=CORE,SOCKET"], capture_output=True, text=True).stdout.splitlines()
+                    if l and not l.startswith("#")})
+    except Exception:
+        phys = 0
+    phys = phys or (os.cpu_count() or 2) // 2
+    P = max(1, phys // per_proc_threads)
+    # memory: a full-size oracle forward peaks below 32 GB (two of them run side by side in the 64 GB build container); never
+    # start more processes than MemAvailable / 32 GB (a host driven out of memory takes the GPU box down with it)
+    try:
+        with open("/proc/meminfo") as f:
+            avail_gb = next(int(l.split()[1]) for l in f if l.startswith("MemAvailable")) / 1048576.0
+    except Exception:
+        avail_gb = 0.0
+    P = min(P, int(avail_gb // 32))
+    if P <= 1:
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    cpus = cpus[:P * per_proc_threads] if len(cpus) >= P * per_proc_threads else cpus
+    P = max(1, len(cpus) // per_proc_threads)
+    child = os.path.join(ROOT, "tools", "cpu_baseline_child.py")
+    procs = []
+    t0 = time.perf_counter()
+    for i in range(P):
+        mine = cpus[i * per_proc_threads:(i + 1) * per_proc_threads]
+        env = dict(os.environ, OMP_NUM_THREADS=str(per_proc_threads), MKL_NUM_THREADS=str(per_proc_threads), HIP_VISIBLE_DEVICES="",
+                   CUDA_VISIBLE_DEVICES="")
+        procs.append(subprocess.Popen([sys.executable, child, str(per_proc_threads), ",".join(map(str, mine)), str(budget_s)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+    res = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=budget_s * 3 + 120)
+            res.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:
+            p.kill()
+    if len(res) < P:
+        return None
+    img = sum(r["img"] for r in res) / len(res)
+    projs = [r["proj"] for r in res if r.get("proj")]
+    proj = (sum(projs) / len(projs)) if projs else None
+    return {"processes": P, "threads_per_process": per_proc_threads, "physical_cores": phys, "img": img, "proj": proj,
+            "wall_s": time.perf_counter() - t0}
 
 
 def main():
@@ -317,7 +363,7 @@ def main():
                 fl[c], ms[c], nl[c] = fl2[c] * args.steps, ms2[c] * args.steps, nl2[c] * args.steps
         # the dominant kernel: whichever kernel of the wide 3x3 stride-1 convolutions carries most time -- class 5 (Winograd
         # domain, 128-cout tiles: conv_wino2) by default, class 3 (64-cout tiles: conv_wino) under wino_v1, class 0 (direct
-        # form) under conv_no_wino / conv_split.  Classes 3 and 5 record EXECUTED flops
+        # form) under conv_no_wino.  Classes 3 and 5 record EXECUTED flops
         dom = max((5, 3, 0), key=lambda c: ms[c])
         if nl[dom]:
             ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
@@ -330,7 +376,7 @@ def main():
                         "avg_launch_gflop": round(fl[dom] / nl[dom] / 1e9, 3)}
             if dom in (3, 5):
                 roofline["reference_form_tflops"] = round(ach * 36.0 / 16.0, 2)     # the same launches counted as 3x3 convolutions
-        names = {5: "conv3x3_winograd_128cout_tiles", 3: "conv3x3_winograd_64cout_tiles", 0: "conv3x3_direct_form", 1: "conv_other", 2: "attention"}
+        names = {5: "conv3x3_winograd_128cout_tiles", 3: "conv3x3_winograd_64cout_tiles", 0: "conv3x3_direct_form", 1: "conv_other", 2: "attention"}      # (4, 6: roofline_hbm / roofline_narrow_readers)
         for c in (5, 3, 0, 1, 2):
             name = names[c]
             if c == dom:
@@ -343,13 +389,23 @@ def main():
                          "untimed step of rank 0 (the other ranks wait at the final barrier), their ms_total / launches scaled to "
                          "%d step(s)" % args.steps)
         if nl[4]:
-            # the bandwidth-bound kernel family: narrow direct convolutions (4/8/16 channels at 2000x912 / 1000x456)
+            # the narrow direct convolutions (conv_direct.hip), split by what bounds them: the layers of the
+            # 4/8/16-channel levels at 2000x912 / 1000x456 (<= 32 input channels: 9-36 FLOP/B) against the HBM peak ...
             gbs = fl[4] / (ms[4] * 1e-3) / 1e9
-            extra["roofline_hbm"] = {"kernel": "conv3x3_direct_kernel<CO> family (conv_direct.hip: narrow layers, packed-f32 VALU)",
+            extra["roofline_hbm"] = {"kernel": "conv_direct_kernel<CO> family, the BANDWIDTH-bound launches: layers of the 4/8/16-channel "
+                                               "levels (<= 32 input channels), packed-f32 VALU",
                                      "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                      "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": int(nl[4]), "ms_total": round(ms[4], 2),
                                      "avg_launch_mb": round(fl[4] / nl[4] / 1e6, 2),
                                      "note": "algorithmic bytes (every input, residual and output element once) / live HIP-event time"}
+        if NC > 6 and nl[6]:
+            # ... and the readers of the 128-channel level (128 + 16 -> 16 at 1000x456: 65 FLOP/B, ridge 20) against the f32 vector peak
+            tf = fl[6] / (ms[6] * 1e-3) / 1e12
+            extra["roofline_narrow_readers"] = {
+                "kernel": "conv_direct_kernel<16,...> on >= 64 input channels (the up-path readers of the 128-channel level): f32 VALU",
+                "bound": "valu_f32", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "launches": int(nl[6]), "ms_total": round(ms[6], 2),
+                "note": "the f32 vector peak equals the f32 MFMA peak on this chip (v_pk_fma_f32: 256 flops / clk / CU)"}
     if rank == 0:
         assert out.shape[0] == n_global and bool(torch.isfinite(out).all())
         value = n_global * args.steps / elapsed
@@ -377,13 +433,11 @@ def main():
                                          "convolutions in the Winograd F(2x2,3x3) domain (16 of 36: " +
                                          ("on" if _lib_option("conv_no_wino") == 0 else "OFF") + ") -- both the same functions in exact "
                                          "arithmetic; the value counts slices, roofline.achieved counts EXECUTED flops only"},
-            "roofline": roofline, "roofline_hbm": extra.pop("roofline_hbm", None), "kernels": extra,
+            "roofline": roofline, "roofline_hbm": extra.pop("roofline_hbm", None),
+            "roofline_narrow_readers": extra.pop("roofline_narrow_readers", None), "kernels": extra,
         }
-        line["dtype"] = {"": "f32", "3": "f32 (wide 3x3 convs: 3-piece split-bf16 operands, 6 MFMA terms, f32 accumulate)",
-                         "2": "f32 (wide 3x3 convs: 2-piece split-bf16 operands, 3 MFMA terms, f32 accumulate)"}.get(
-                             os.environ.get("IPDM_CONV_SPLIT", ""), "f32")
         ref_shape = not alt and not img_only
-        if world == 1 and not args.no_extra_legs and ref_shape and not os.environ.get("IPDM_CONV_SPLIT"):
+        if world == 1 and not args.no_extra_legs and ref_shape:
             # ---- B = 1 latency (the reference is a one-slice-at-a-time tool): same workload, one slice
             den.data_sample_load(ldproj=ldproj[:1].contiguous())
 
@@ -447,41 +501,10 @@ def main():
                             "t_start_img=%s, constant guidance %.2f, no ultra pass (BASELINE config C2)" % (
                                 B, sum(args.t_start_img), args.t_start_img, opt.constant_guidance_img),
                 "value": round(B / dti, 5), "unit": "slices/s", "ms_per_step": round(dti * 1e3, 2), "steps": 1}
-        if world == 1 and not args.no_alt and ref_shape and not os.environ.get("IPDM_CONV_SPLIT"):
-            # opt-in mode measured beside the headline (never the headline): same workload, same inputs
+        if world == 1 and not args.no_alt and ref_shape:
+            from ipdm_pytorch_amd.diffusion import NoiseSource
             del den
-            torch.cuda.empty_cache()
-            _lib.set_option("conv_split", 3)
-            _lib.set_option("attn_split", 3)
-            try:
-                from ipdm_pytorch_amd.diffusion import NoiseSource
-                den2 = progressive_domain_denoiser(opt, seed=1234, slice_id0=lo)
-                den2.data_sample_load(ldproj=ldproj)
-                out2 = den2.progressive_denoiser_device(sharpen_num=70)
-                # the compared pass replays exactly the draws of the headline's last timed step: same seed, same
-                # global slice ids, same draw indices (the counter-based source is a pure function of the three)
-                den2.noise = NoiseSource(1234, lo)
-                den2.noise.draw = draw0
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                out2 = den2.progressive_denoiser_device(sharpen_num=70)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t1
-                assert den2.noise.draw - draw0 == draws_per_step, "alt mode consumed a different draw range"
-                d = (out2 - out).float()
-                mse = float((d * d).mean())
-                rng = float(out.max() - out.min())
-                line["alt_modes"] = {"IPDM_CONV_SPLIT=3 IPDM_ATTN_SPLIT=3": {
-                    "value": round(n_global / dt, 5), "unit": "slices/s", "ms_per_step": round(dt * 1e3, 2), "steps": 1,
-                    "psnr_vs_default_db": round(10 * math.log10(rng * rng / mse), 2) if mse > 0 else None,
-                    "note": "wide 3x3 convs and attention as 3-piece split-bf16 (6 bf16 MFMA terms per product, f32 accumulate); "
-                            "kernel- and network-level parity tests pass at the exact-f32 tolerances, float64 study in DESIGN 6c "
-                            "(the reduced end-to-end pipeline's 6e-4 max-abs bound against the f32 CPU oracle, E2E_MAX_REL of the test suite, holds in this mode too); "
-                            "not the headline"}}
-                del den2
-            finally:
-                _lib.set_option("conv_split", 0)
-                _lib.set_option("attn_split", 0)
+            line["alt_modes"] = {}
             # the headline's one algebraic shortcut switched off: every Upsample layer as the reference's 3x3 convolution over
             # the nearest-upsampled image (9 instead of 4 multiply-adds per output): all 85.1 TFLOP per slice executed
             torch.cuda.empty_cache()
@@ -522,6 +545,23 @@ def main():
                           "%d logical cores, %d at most) timed on 1 proj-UNet fwd @2000x912 (%.1fs), 1 img-UNet fwd @512x512 (%.1fs), "
                           "1 FBP (%.1fs); extrapolated by call counts %d/%d/1 per slice" % (cores, used, tb["proj"], tb["img"], tb["fbp"], n_fwd_proj, n_fwd_img)}
             line["speedup_vs_cpu_baseline"] = round(value * per_slice, 1)
+            # the host-filling figure beside it: P independent oracle processes on disjoint core sets, all running at once
+            hb = cpu_baseline_host(16, n_fwd_proj, n_fwd_img)
+            if hb:
+                # (a child that had no budget left for the proj forward: scale the single-process one by the img slow-down)
+                proj_t = hb["proj"] if hb["proj"] else tb["proj"] * hb["img"] / tb["img"]
+                per_slice_h = n_fwd_proj * proj_t + n_fwd_img * hb["img"] + tb["fbp"]
+                line["cpu_baseline"]["value_host"] = round(hb["processes"] / per_slice_h, 6)
+                line["cpu_baseline"]["host"] = {
+                    "processes": hb["processes"], "threads_per_process": hb["threads_per_process"], "physical_cores": hb["physical_cores"],
+                    "cores": hb["processes"] * hb["threads_per_process"],
+                    "sample": "P = %d independent oracle processes pinned to disjoint %d-core sets, all running at once: img-UNet fwd "
+                              "%.1fs, proj-UNet fwd %s per process; per slice by the same call counts %d/%d/1; value_host = P / that "
+                              "(the reference's loop is one slice at a time, so slices are what a host parallelises over)" % (
+                                  hb["processes"], hb["threads_per_process"], hb["img"],
+                                  ("%.1fs" % hb["proj"]) if hb["proj"] else "not timed (scaled by the img slow-down)", n_fwd_proj, n_fwd_img),
+                    "wall_s": round(hb["wall_s"], 1)}
+                line["speedup_vs_cpu_baseline_host"] = round(value / line["cpu_baseline"]["value_host"], 1)
         print(json.dumps(line))
     if torch.distributed.is_initialized():
         idist.barrier()          # (rank 0 ran its untimed profiling step and printed the line: leave together)

@@ -31,14 +31,14 @@ extern "C" {
 #define IPDM_ERR_UNSUPPORTED (-4)
 
 const char *ipdm_last_error(void);
-/* ABI version of this header (bumped on any signature change or new entry point): 3. */
+/* ABI version of this header (bumped on any signature change or new entry point): 4. */
 int ipdm_abi_version(void);
 
 /* Process-wide switches of the library (A/B experiments, opt-in evaluation modes); no reference counterpart -- the
  * reference's only knobs are its option keys (Config/default_config.py), which stay in the Python layer.
- * `name` is lower case, e.g. "conv_split" (0 | 2 | 3: split-bf16 evaluation of the wide 3x3 convolutions), "attn_split"
- * (0 | 3), "conv_no_up2" (Upsample layers in the reference's 3x3 form), "conv_no_wino", "gn_unfused", "unet_transpose"
- * (-1 | 0 | 1) ...; README.md lists them.  Every switch starts from the environment variable IPDM_<NAME> (read once, kept
+ * `name` is lower case, e.g. "conv_no_up2" (Upsample layers in the reference's 3x3 form), "conv_no_wino", "gn_unfused",
+ * "unet_transpose" (-1 | 0 | 1), "conv_nm" (0 | 1 | 2: the opt-in 16-cout MFMA form of the narrow layers) ...;
+ * README.md lists them.  Every switch starts from the environment variable IPDM_<NAME> (read once, kept
  * as a debug alias) and changes only through this call afterwards.  Switches that shape packed weights or kernel choice
  * are recorded by ipdm_unet_create: a forward on a handle created under other values fails with IPDM_ERR_INVALID instead
  * of running on a mismatched layout; per-call switches (conv_no_up2, conv_no_wino, conv_no_pw, pw_item, pw_force, wino_v1, wino2_min_tiles, conv1x1_no_quarter, conv_nm, direct_no_skip_fuse, gn_unfused,
@@ -260,10 +260,12 @@ int ipdm_art_project(ipdm_art_plan *plan, const float *d_volume, float *d_proj, 
  * stride-1 wide tile in its direct form, 1 = other conv variants, 2 = attention, 3 = the Winograd-domain form of
  * class 0's layers (recorded with its EXECUTED flops, 16/36 of the 3x3 count), 4 = the narrow direct convolutions
  * (bandwidth-bound: `out_flops[4]` holds their algorithmic HBM BYTES), 5 = the 128-cout-tile Winograd kernel
- * (conv_wino2, the dominant kernel; class 3 keeps the 64-cout-tile one).  ipdm_profile_end needs the stream
+ * (conv_wino2, the dominant kernel; class 3 keeps the 64-cout-tile one), 6 = the narrow direct convolutions that read a
+ * wide tensor (>= 64 input channels: bound by the f32 vector ALU, recorded with their flops; class 4 keeps the
+ * bandwidth-bound ones).  ipdm_profile_end needs the stream
  * synchronised; outputs are arrays of `n_classes` >= IPDM_PROF_CLASSES entries (a shorter array is an error, not an
  * overflow). */
-#define IPDM_PROF_CLASSES 6
+#define IPDM_PROF_CLASSES 7
 int ipdm_profile_begin(int32_t max_launches);
 /* ... recording only the classes whose bit is set in class_mask (an event pair costs the stream about a microsecond per
  * launch: bench.py times its headline with the dominant kernel's classes only and the rest on an extra, untimed pass) */
@@ -280,8 +282,8 @@ int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, int32_t W, i
                       int32_t stride, int32_t act, int32_t with_res, int32_t iters, float *avg_ms);
 int ipdm_bench_attention(int32_t B, int32_t heads, int32_t d, int32_t T, int32_t iters, float *avg_ms);
 /* Which kernel family a convolution of this shape is packed for NOW (the environment switches are read when
- * weights are packed): 0 = plain layout (direct / legacy kernels), 2 | 4 = conv_ws cout-interleaved f32 MFMA,
- * 102 | 103 = opt-in split-bf16 (IPDM_CONV_SPLIT=2|3).  Test aid: lets a parity test prove which path it ran. */
+ * weights are packed): 0 = plain layout (direct / legacy kernels), 2 | 4 = conv_ws cout-interleaved f32 MFMA.
+ * Test aid: lets a parity test prove which path it ran. */
 int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
 /* Which KERNEL a plain convolution (one source, no resampling on the way in, K-split workspace available) of this shape
  * and batch takes NOW -- the dispatch of the executor's conv2d_launch, options included:
@@ -291,11 +293,11 @@ int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
  *   7 = parity form of an Upsample (never for this plain shape)   8 = conv_igemm (the generic 4-wave kernel)
  *   9 = conv_wino2 with K slices + combine pass (the layers with too few tiles per sample)
  *   10 = conv_pw (wide 1x1 layers: the barrier-free pointwise kernel)
- *   102 | 103 = opt-in split-bf16;  -1 = bad argument.
+ *   -1 = bad argument.
  * Test aid (replaces nothing in the reference): a parity test asserts the kernel it believes it covers. */
 int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W);
 /* Which attention kernel a launch with head dim d takes NOW: 0 = 4-wave kernel (d = 32, or IPDM_ATTN_LEGACY),
- * 1 = wave-specialised exact-f32 MFMA (the default for d = 64), 3 = opt-in split-bf16 (IPDM_ATTN_SPLIT=3). */
+ * 1 = wave-specialised exact-f32 MFMA (the default for d = 64). */
 int32_t ipdm_attention_kernel_code(int32_t d);
 
 #ifdef __cplusplus

@@ -484,10 +484,8 @@ namespace ipdm {
 
 size_t attention_scratch_floats(int B, int heads, int d, int T)
 {
-    const size_t sx = d == 64 ? attention_sx_scratch_floats(B, heads, T) : 0;
     const int Z = attention_kv_split(B, heads, d, T);
-    const size_t kvs = Z > 1 ? (size_t)Z * B * heads * (d + 2) * T : 0;
-    return sx > kvs ? sx : kvs;
+    return Z > 1 ? (size_t)Z * B * heads * (d + 2) * T : 0;
 }
 
 int attention_launch(const float *qkv, float *out, int B, int heads, int d, int T, hipStream_t st, float *scratch)
@@ -499,10 +497,7 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
     const bool prof = prof_enabled();
     if (prof) prof_before(2, st);
     const bool legacy = opt(OPT_ATTN_LEGACY) != 0;
-    if (d == 64 && opt(OPT_ATTN_SPLIT) == 3) {
-        const int rc = attention_sx_launch(qkv, scratch, out, B, heads, T, scale, st);
-        if (rc) return rc;
-    } else if (d == 64 && !legacy) {
+    if (d == 64 && !legacy) {
         // wave-specialised kernel, one 512-thread workgroup per CU.  64 queries per consumer wave (K/V operand reads
         // shared by two query tiles) when the 256-query workgroups come in whole rounds of the CUs, else 32
         constexpr size_t lds = (size_t)2 * (KV * KP + 64 * VP) * sizeof(float);
@@ -542,7 +537,6 @@ int attention_launch(const float *qkv, float *out, int B, int heads, int d, int 
 
 extern "C" int32_t ipdm_attention_kernel_code(int32_t d)
 {
-    if (d == 64 && ipdm::opt(ipdm::OPT_ATTN_SPLIT) == 3) return 3;
     return (d == 64 && !ipdm::opt(ipdm::OPT_ATTN_LEGACY)) ? 1 : 0;
 }
 

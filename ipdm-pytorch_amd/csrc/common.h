@@ -41,12 +41,10 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // an entry that shapes packed weights, workspace layout or kernel choice differs from that record (OPT_PER_CALL entries
 // excepted), so a switch flipped between create and forward is an error, not a silently mismatched layout.
 enum Opt {
-    OPT_CONV_SPLIT,          // 0 | 2 | 3: opt-in split-bf16 evaluation of the wide 3x3 convolutions (weights packed for it)
-    OPT_ATTN_SPLIT,          // 0 | 3: opt-in split-bf16 attention
     OPT_CONV_NO_UP2,         // Upsample layers in the reference's 3x3 form (per call: both weight sets are packed)
     OPT_CONV_LEGACY, OPT_CONV1X1_LEGACY, OPT_CONVS2_LEGACY,      // route kernel families to the round-1 4-wave kernels
     OPT_CONV_NO_DIRECT, OPT_DIRECT_NO_PLANAR, OPT_DIRECT_MAX_CIN, OPT_DIRECT_NO_S2, OPT_DIRECT_NO_SKIP_FUSE,
-    OPT_CONV_SX_CW2, OPT_CONV_DBG, OPT_CONV_VEC4_STRICT, OPT_CONV_NO_SPLITK, OPT_CONV_NO_WINO, OPT_WINO_V1, OPT_WINO2_MIN_TILES, OPT_CONV1X1_NO_QUARTER, OPT_CONV_NO_PW, OPT_PW_ITEM, OPT_PW_FORCE,
+    OPT_CONV_DBG, OPT_CONV_VEC4_STRICT, OPT_CONV_NO_SPLITK, OPT_CONV_NO_WINO, OPT_WINO_V1, OPT_WINO2_MIN_TILES, OPT_CONV1X1_NO_QUARTER, OPT_CONV_NO_PW, OPT_PW_ITEM, OPT_PW_FORCE,
     OPT_CONV_NM,             // opt-in: narrow stride-1 layers on the 16-cout MFMA (conv_nm.hip): 1 = 16-cout layers, 2 = 8-cout too
     OPT_GN_TWO_STAGE, OPT_GN_UNFUSED,
     OPT_UNET_TRANSPOSE,      // -1 automatic | 0 never | 1 always

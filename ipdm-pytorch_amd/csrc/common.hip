@@ -26,12 +26,12 @@ int g_cus[64];                                         // per device ordinal, 0 
 namespace {
 struct OptDef { const char *name; int def; bool per_call; int lo = 0, hi = 1; };      // [lo, hi]: what ipdm_set_option accepts
 const OptDef g_opt_def[OPT_COUNT] = {
-    {"conv_split", 0, false, 0, 3}, {"attn_split", 0, false, 0, 3}, {"conv_no_up2", 0, true},
+    {"conv_no_up2", 0, true},
     {"conv_legacy", 0, false}, {"conv1x1_legacy", 0, false}, {"convs2_legacy", 0, false},
     {"conv_no_direct", 0, false}, {"direct_no_planar", 0, false},
     {"direct_max_cin", 160, false, 0, 160},      // (conv_direct's LDS staging and chunk loop are sized for at most 160 input channels)
     {"direct_no_s2", 0, false}, {"direct_no_skip_fuse", 0, true},
-    {"conv_sx_cw2", 0, false}, {"conv_dbg", 0, true, 0, 0x3ff}, {"conv_vec4_strict", 0, false}, {"conv_no_splitk", 0, false},
+    {"conv_dbg", 0, true, 0, 0x3ff}, {"conv_vec4_strict", 0, false}, {"conv_no_splitk", 0, false},
     {"conv_no_wino", 0, true}, {"wino_v1", 0, true}, {"wino2_min_tiles", 192, true, 0, 1 << 24},
     {"conv1x1_no_quarter", 0, true}, {"conv_no_pw", 0, true}, {"pw_item", 0, true, 0, 2}, {"pw_force", 0, true}, {"conv_nm", 0, true, 0, 2},
     {"gn_two_stage", 0, true}, {"gn_unfused", 0, true},
@@ -41,10 +41,7 @@ const OptDef g_opt_def[OPT_COUNT] = {
 };
 bool opt_value_ok(int i, int v)
 {
-    if (v < g_opt_def[i].lo || v > g_opt_def[i].hi) return false;
-    if (i == OPT_CONV_SPLIT) return v == 0 || v == 2 || v == 3;
-    if (i == OPT_ATTN_SPLIT) return v == 0 || v == 3;
-    return true;
+    return v >= g_opt_def[i].lo && v <= g_opt_def[i].hi;
 }
 std::mutex g_opt_mu;
 int g_opt_val[OPT_COUNT];
@@ -135,14 +132,14 @@ int device_cu_count()
 }  // namespace ipdm
 
 extern "C" const char *ipdm_last_error(void) { return ipdm::g_err; }
-extern "C" int ipdm_abi_version(void) { return 3; }      // 2: ipdm_profile_end takes its array length; ipdm_conv_kernel_code  3: ipdm_profile_begin_classes
+extern "C" int ipdm_abi_version(void) { return 4; }      // 2: ipdm_profile_end takes its array length; ipdm_conv_kernel_code  3: ipdm_profile_begin_classes  4: profile class 6 (IPDM_PROF_CLASSES 7); the split-bf16 switches are gone
 
 extern "C" int ipdm_set_option(const char *name, int value)
 {
     const int i = ipdm::opt_find(name);
     IPDM_REQUIRE(i >= 0, "ipdm_set_option: unknown option '%s'", name ? name : "(null)");
-    IPDM_REQUIRE(ipdm::opt_value_ok(i, value), "ipdm_set_option: %s = %d is outside [%d, %d]%s", ipdm::g_opt_def[i].name, value,
-                 ipdm::g_opt_def[i].lo, ipdm::g_opt_def[i].hi, (i == ipdm::OPT_CONV_SPLIT || i == ipdm::OPT_ATTN_SPLIT) ? " (or not one of its modes)" : "");
+    IPDM_REQUIRE(ipdm::opt_value_ok(i, value), "ipdm_set_option: %s = %d is outside [%d, %d]", ipdm::g_opt_def[i].name, value,
+                 ipdm::g_opt_def[i].lo, ipdm::g_opt_def[i].hi);
     std::lock_guard<std::mutex> lk(ipdm::g_opt_mu);
     ipdm::opt_init_locked();
     ipdm::g_opt_val[i] = value;

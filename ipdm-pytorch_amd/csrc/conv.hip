@@ -373,7 +373,6 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
     const bool wide = a.Cout > 32;
     // wide 3x3 convolutions (>80 % of the path's FLOPs) run on the persistent wave-specialised kernel (conv_ws.hip);
     // when their weights were packed for it (conv_weight_interleave); IPDM_CONV_LEGACY=1 at pack time keeps them here
-    if (conv_sx_pieces(a.w_interleave)) return conv2d_sx_launch(a, st);
     if (a.w_interleave) return conv_pw_eligible(a) ? conv2d_pw_launch(a, st) : conv2d_ws_launch(a, st);      // (1x1: conv_pw.hip)
     if (!opt(OPT_CONV_NO_DIRECT) && conv_direct_eligible(a)) return conv2d_direct_launch(a, st);
     if (a.ksize == 3 && a.stride == 1) return wide ? launch_conv<3, 1, 2, 2, 8>(a, st) : launch_conv<3, 1, 1, 2, 8>(a, st);
@@ -386,7 +385,6 @@ int conv2d_launch(const ConvArgs &a, hipStream_t st)
 // mirrors the dispatch of conv2d_launch: WHICH kernel this convolution runs on now (ipdm_conv_kernel_code)
 int conv_kernel_code(const ConvArgs &a)
 {
-    if (conv_sx_pieces(a.w_interleave)) return 100 + conv_sx_pieces(a.w_interleave);
     if (a.w_interleave) {
         if (conv_pw_eligible(a)) return 10;
         if (conv_up2_eligible(a)) return 7;
@@ -403,7 +401,6 @@ int conv_kernel_code(const ConvArgs &a)
 // mirrors the dispatch of conv2d_launch: rows of fused output statistics of the kernel this convolution runs on
 int conv_stats_rows(const ConvArgs &a)
 {
-    if (conv_sx_pieces(a.w_interleave)) return 0;                       // opt-in split-bf16 kernels: no fused statistics
     if (a.w_interleave) return conv_pw_stats_layer(a) ? conv_pw_stats_rows(a) : conv_ws_stats_rows(a);      // (asked for layers that want statistics)
     if (!opt(OPT_CONV_NO_DIRECT) && conv_direct_eligible(a)) return conv_direct_stats_rows(a);
     return a.Ho * cdiv(a.Wo, 32);                                       // the 4-wave kernels below: a row per pixel row and tile column
@@ -411,7 +408,7 @@ int conv_stats_rows(const ConvArgs &a)
 
 int conv_split(const ConvArgs &a)
 {
-    if (conv_sx_pieces(a.w_interleave) || !a.w_interleave || conv_pw_layer_ok(a)) return 1;      // (conv_pw's layers are never K-split ones)
+    if (!a.w_interleave || conv_pw_layer_ok(a)) return 1;      // (conv_pw's layers are never K-split ones)
     if (conv_wino_eligible(a)) return conv_ws_split(a) > 1 ? conv_wino_split(a) : 1;      // (K slices inside conv_wino2)
     return conv_ws_split(a);
 }
@@ -422,7 +419,7 @@ size_t conv_split_ws_bytes(const ConvArgs &a)
 }
 
 int conv_k_chunk() { return 8; }
-int conv_ws_k_chunk(int ks, int interleave) { return conv_sx_pieces(interleave) ? 16 : ((interleave && ks == 1) ? 32 : 8); }
+int conv_ws_k_chunk(int ks, int interleave) { return (interleave && ks == 1) ? 32 : 8; }
 
 // Up-sampling convolution (nearest 2x, then 3x3, zero padding 1): output pixel (2y + a, 2x + b) reads the source pixels
 // (y + i + a - 1, x + j + b - 1), i, j in {0, 1}; the 3x3 taps that land on the same source pixel are
@@ -453,7 +450,6 @@ void conv_pack_weights_up2(const float *w, int Cout, int Cin, int interleave, st
 bool conv_planar_ok(const ConvArgs &a)
 {
     if (a.upsample || (a.Hs & 1) || (a.Ws & 1)) return false;
-    if (conv_sx_pieces(a.w_interleave)) return false;
     if (a.w_interleave && conv_pw_layer_ok(a)) return true;            // (either kernel such a layer can land on reads parity-planar x1)
     if (a.w_interleave) return conv_ws_planar_ok(a);                    // the wave-specialised kernels (conv_ws.hip)
     // (the stride-2 direct kernel and the 4-wave kernels below read NCHW only)
@@ -486,10 +482,6 @@ int planar_to_linear_launch(const float *src, float *dst, long planes, int H, in
 int conv_weight_interleave(int Cout, int ks, int stride)
 {
     const bool legacy = opt(OPT_CONV_LEGACY) != 0, legacy1 = opt(OPT_CONV1X1_LEGACY) != 0, legacy2 = opt(OPT_CONVS2_LEGACY) != 0;
-    // conv_split = 3 (6-term, fp32-equivalent) or 2 (3-term): opt-in split-bf16 evaluation of the wide 3x3 stride-1 convs
-    // (read at every pack: one process may hold nets of both modes -- bench.py's alt leg, the split parity tests)
-    const int split = opt(OPT_CONV_SPLIT);
-    if (!legacy && (split == 2 || split == 3) && ks == 3 && stride == 1 && Cout > 32) return 100 + split;
     if (legacy || Cout <= 32 || (ks != 3 && ks != 1) || (ks == 1 && (legacy1 || stride != 1)) || stride > 2 || (stride == 2 && legacy2))
         return 0;
     return Cout > 96 ? 4 : 2;       // 128-cout tiles (MB=4,NB=2) for the wide layers, 64-cout x 16-row tiles (MB=2,NB=4) otherwise
@@ -501,10 +493,6 @@ int conv_weight_interleave(int Cout, int ks, int stride)
 void conv_pack_weights(const float *w, int Cout, int Cin, int ks, int interleave, std::vector<float> &packed, int &cin_pad,
                        int &cout_pad)
 {
-    if (conv_sx_pieces(interleave)) {
-        conv_sx_pack_weights(w, Cout, Cin, conv_sx_pieces(interleave), packed, cin_pad, cout_pad);
-        return;
-    }
     const int group = interleave ? 32 * interleave : 64;
     const int kc = conv_ws_k_chunk(ks, interleave);           // channels per K chunk of the kernel that will read the slab
     cin_pad = (Cin + kc - 1) / kc * kc;

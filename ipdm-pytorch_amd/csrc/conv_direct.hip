@@ -36,6 +36,18 @@ inline double direct_bytes(const ConvArgs &a)
     return 4.0 * a.B * ((double)(a.C1 + a.C2 + (a.sk_w ? a.sk_C1 + a.sk_C2 : 0)) * a.Hs * a.Ws + (double)a.Cout * a.Ho * a.Wo * (a.res ? 2 : 1));
 }
 
+// The family holds two kinds of launches: the layers of the 4/8/16-channel levels (up to 32 input channels with a
+// concatenated skip: 9-36 FLOP/B, BANDWIDTH-bound: class 4, recorded with their algorithmic bytes) and the readers of the
+// 128-channel level -- 128 + 16 -> 16 at 1000x456, 65 FLOP/B against a ridge of 20 -- which are bound by the f32 VALU
+// (class 6, recorded with their flops)
+inline bool direct_compute_bound(const ConvArgs &a) { return a.C1 + a.C2 >= 64; }
+inline double direct_flops(const ConvArgs &a, int taps)
+{
+    return 2.0 * a.B * a.Ho * a.Wo * a.Cout * ((double)(a.C1 + a.C2) * taps + (a.sk_w ? a.sk_C1 + a.sk_C2 : 0));
+}
+inline int direct_class(const ConvArgs &a) { return direct_compute_bound(a) ? 6 : 4; }
+inline double direct_work(const ConvArgs &a, int taps) { return direct_compute_bound(a) ? direct_flops(a, taps) : direct_bytes(a); }
+
 constexpr int DT_W = 64, DT_H = 16;
 
 // Which tile a workgroup takes.  Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), so with
@@ -391,9 +403,9 @@ int launch_direct_s2(const ConvArgs &a, hipStream_t st)
 {
     dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
     const bool prof = prof_enabled();
-    if (prof) prof_before(4, st);
+    if (prof) prof_before(direct_class(a), st);
     hipLaunchKernelGGL((conv_direct_kernel<CO, 3, 2, false, 2>), grid, dim3(256), 0, st, a);
-    if (prof) prof_after(4, direct_bytes(a), st);
+    if (prof) prof_after(direct_class(a), direct_work(a, 9), st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }
@@ -403,19 +415,19 @@ int launch_direct(const ConvArgs &a, hipStream_t st)
 {
     dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
     const bool prof = prof_enabled();
-    if (prof) prof_before(4, st);
+    if (prof) prof_before(direct_class(a), st);
     if constexpr (KS == 3 && CO >= 8) {
         if (a.sk_w) {
             if (a.sk_planar) hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), false, 1, 2>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), false, 1, 1>), grid, dim3(256), 0, st, a);
-            if (prof) prof_after(4, direct_bytes(a), st);
+            if (prof) prof_after(direct_class(a), direct_work(a, KS * KS), st);
             IPDM_LAUNCH_CHECK();
             return IPDM_OK;
         }
     }
     if (a.x1_planar) hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_direct_kernel<CO, KS, (CO <= 8 ? 4 : 8), false>), grid, dim3(256), 0, st, a);
-    if (prof) prof_after(4, direct_bytes(a), st);
+    if (prof) prof_after(direct_class(a), direct_work(a, KS * KS), st);
     IPDM_LAUNCH_CHECK();
     return IPDM_OK;
 }
@@ -480,7 +492,7 @@ int conv2d_direct_launch(const ConvArgs &a, hipStream_t st)
     if (conv_direct_up2_eligible(a)) {
         dim3 grid(cdiv(a.Wo, DT_W), cdiv(a.Ho, DT_H), a.B);
         const bool prof = prof_enabled();
-        if (prof) prof_before(4, st);
+        if (prof) prof_before(4, st);      // (parity form of a narrow Upsample: 16 -> 16, bandwidth-bound)
         if (a.Cout <= 8) hipLaunchKernelGGL((conv_direct_up2_kernel<8, 8>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_direct_up2_kernel<16, 8>), grid, dim3(256), 0, st, a);
         if (prof) prof_after(4, direct_bytes(a), st);

@@ -781,8 +781,7 @@ struct Fwd {
         gn(x, nullptr, ap.n);
         Tensor *qkv = conv(x, nullptr, ap.qkv, 1, 1, nullptr, nullptr, H, W);
         Tensor *a = make(x->C, H, W);
-        // scratch of the opt-in split-bf16 attention (pre-split K/V tile images); carved in every mode so that the
-        // workspace walk does not depend on the environment
+        // scratch of the key-slice split (partial outputs of short sequences), a rule of the layer's shape
         const int heads = net->cfg.num_heads, hd = x->C / heads;
         const size_t sfl = attention_scratch_floats(net->B, heads, hd, H * W);
         Tensor *scr = sfl ? make((int)((sfl + (size_t)net->B * H * W - 1) / ((size_t)net->B * H * W)), H, W) : nullptr;
@@ -1385,7 +1384,7 @@ extern "C" int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, i
     a.x1 = &dummy; a.x2 = nullptr; a.C1 = Cin; a.C2 = 0; a.B = B; a.Hs = H; a.Ws = W; a.H = H; a.W = W; a.upsample = 0;
     a.scale_y = a.scale_x = 1.f; a.w = &dummy; a.bias = nullptr; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
     a.w_interleave = conv_weight_interleave(Cout, ksize, stride);
-    const int group = conv_sx_pieces(a.w_interleave) ? 64 : (a.w_interleave ? 32 * a.w_interleave : 64);      // (conv_pack_weights)
+    const int group = a.w_interleave ? 32 * a.w_interleave : 64;      // (conv_pack_weights)
     a.cout_pad = (Cout + group - 1) / group * group;
     a.Ho = (H + 2 * pad - ksize) / stride + 1; a.Wo = (W + 2 * pad - ksize) / stride + 1;
     a.act = 0; a.gn_scale = a.gn_shift = nullptr; a.res = nullptr; a.out = &dummy;

@@ -5,6 +5,20 @@
 
 namespace ipdm {
 
+// The same statistics from the per-tile partial sums the producing convolutions left behind (ConvArgs::stats) instead of
+// a pass over the activations: up to two sources (channel concat), each [B][rows][C][2] float32.
+struct GnTileSrc { const float *stats = nullptr; int rows = 0, C = 0; };
+struct GnTileArgs {
+    GnTileSrc src[2];
+    int nsrc = 1, B = 0;
+    long HW = 0;
+    int groups = 0;
+    const float *gamma = nullptr, *beta = nullptr;
+    float eps = 1e-5f;
+    double *partials = nullptr;            // [B, groups, GN_SPLIT, 2]
+    float *scale = nullptr, *shift = nullptr;        // [B, C1+C2]
+};
+
 struct ConvArgs {
     const float *x1, *x2;        // sources [B,C1,Hs,Ws], [B,C2,Hs,Ws] (x2 may be null)
     int C1, C2, B;
@@ -60,10 +74,6 @@ struct ConvArgs {
 int conv2d_launch(const ConvArgs &a, hipStream_t st);
 int conv_kernel_code(const ConvArgs &a);                  // which kernel conv2d_launch would take (codes: include/ipdm_hip.h)
 int conv2d_ws_launch(const ConvArgs &a, hipStream_t st);   // persistent wave-specialised variant (conv_ws.hip)
-// opt-in split-bf16 evaluation of the wide 3x3 convolutions (conv_sx.hip); weight layout code 100 + pieces
-int conv_sx_pieces(int interleave);
-void conv_sx_pack_weights(const float *w, int Cout, int Cin, int ns, std::vector<float> &packed, int &cin_pad, int &cout_pad);
-int conv2d_sx_launch(const ConvArgs &a, hipStream_t st);
 bool conv_direct_eligible(const ConvArgs &a);             // narrow layers: direct packed-f32 VALU kernel (conv_direct.hip)
 int conv2d_direct_launch(const ConvArgs &a, hipStream_t st);
 bool conv_nm_eligible(const ConvArgs &a);                 // ... of those, the stride-1 layers that run on the 16-cout MFMA (conv_nm.hip)
@@ -76,7 +86,8 @@ int conv_ws_k_chunk(int ks, int interleave);   // K chunk of the kernel a (ks, w
 // 3 = the Winograd-domain form of class 0's layers, recorded with its EXECUTED flops (16/36 of the 3x3 count)
 // 4 = the narrow direct convolutions (conv_direct.hip), bandwidth-bound: recorded with their algorithmic HBM BYTES
 // 5 = the 128-cout-tile Winograd kernel (conv_wino2.hip; class 3 keeps the 64-cout-tile kernel), EXECUTED flops
-constexpr int PROF_CLASSES = 6;
+// 6 = the narrow direct convolutions that READ a wide tensor (>= 64 input channels): f32-VALU-bound, recorded with their flops
+constexpr int PROF_CLASSES = 7;
 bool prof_enabled();
 void prof_before(int cls, hipStream_t st);
 void prof_after(int cls, double flops, hipStream_t st);
@@ -98,19 +109,6 @@ struct GnArgs {
     int split = 0;               // workgroups per (sample, group), chosen by the launcher (<= GN_SPLIT)
 };
 constexpr int GN_SPLIT = 64;
-// The same statistics from the per-tile partial sums the producing convolutions left behind (ConvArgs::stats) instead of
-// a pass over the activations: up to two sources (channel concat), each [B][rows][C][2] float32.
-struct GnTileSrc { const float *stats = nullptr; int rows = 0, C = 0; };
-struct GnTileArgs {
-    GnTileSrc src[2];
-    int nsrc = 1, B = 0;
-    long HW = 0;
-    int groups = 0;
-    const float *gamma, *beta;
-    float eps;
-    double *partials;            // [B, groups, GN_SPLIT, 2]
-    float *scale, *shift;        // [B, C1+C2]
-};
 int gn_tiles_launch(const GnTileArgs &a, hipStream_t st);
 // rows of ConvArgs::stats per sample the kernel chosen for this convolution writes (0: that kernel has no fused statistics)
 int conv_stats_rows(const ConvArgs &a);
@@ -145,12 +143,9 @@ int conv_direct_stats_rows(const ConvArgs &a);
 size_t gn_partials_bytes(int B, int groups);
 int gn_stats_launch(const GnArgs &a, hipStream_t st);
 
-// scratch: attention_scratch_floats() floats, used only by the opt-in split-bf16 variant (may be null otherwise)
+// scratch: attention_scratch_floats() floats (the partial outputs of the key-slice split; null: never split)
 int attention_launch(const float *qkv, float *out, int B, int heads, int d, int T, hipStream_t st, float *scratch = nullptr);
 size_t attention_scratch_floats(int B, int heads, int d, int T);
-// opt-in split-bf16 variant (attn_sx.hip, IPDM_ATTN_SPLIT=3), d = 64 only
-size_t attention_sx_scratch_floats(int B, int heads, int T);
-int attention_sx_launch(const float *qkv, float *scratch, float *out, int B, int heads, int T, float scale, hipStream_t st);
 
 // time embedding: emb = Linear(SiLU(Linear(sinusoid(t)))) ; out = SiLU(emb)  (Model/model.py:14-32,218-222,105-108)
 int temb_launch(const float *freqs, int mc, int t, const float *w0, const float *b0, const float *w2, const float *b2,

@@ -41,7 +41,7 @@ def test_host_only_entry_points():
     """Schedule tables and UNet parameter inventory are host code: callable without a GPU."""
     from ipdm_pytorch_amd import _lib
     lib = _lib.lib()
-    assert lib.ipdm_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.ipdm_abi_version() == _lib.ABI_VERSION == 4
     out = C.c_double()
     _lib.call("ipdm_cosine_lambda", 15, 1.0, 3, C.byref(out))
     assert 0.0 <= out.value <= 0.999
@@ -78,7 +78,7 @@ def test_errors_are_status_codes_not_exceptions():
 def test_options_table_without_a_gpu():
     """ipdm_set_option / ipdm_get_option are host-only: defaults, the IPDM_ prefix alias, unknown names."""
     from ipdm_pytorch_amd import _lib
-    assert _lib.get_option("conv_split") == 0 and _lib.get_option("direct_max_cin") == 160 and _lib.get_option("unet_transpose") == -1
+    assert _lib.get_option("conv_nm") == 0 and _lib.get_option("direct_max_cin") == 160 and _lib.get_option("unet_transpose") == -1
     with _lib.option("conv_no_up2", 1):
         assert _lib.get_option("IPDM_CONV_NO_UP2") == 1
     assert _lib.get_option("conv_no_up2") == 0
@@ -92,20 +92,23 @@ def test_option_values_are_range_checked():
     graph key or a kernel's static limits must never see them."""
     from ipdm_pytorch_amd import _lib
     lib = _lib.lib()
-    for name, bad in (("conv_nm", 4), ("wino2_min_tiles", -1), ("unet_transpose", 2), ("direct_max_cin", 4096), ("conv_split", 1),
+    for name, bad in (("conv_nm", 4), ("wino2_min_tiles", -1), ("unet_transpose", 2), ("direct_max_cin", 4096), ("pw_item", 3),
                       ("conv_no_wino", 7)):
         old = _lib.get_option(name)
         rc = lib.ipdm_set_option(name.encode(), bad)
         assert rc != 0 and name.encode() in lib.ipdm_last_error(), (name, rc, lib.ipdm_last_error())
         assert _lib.get_option(name) == old
-    with _lib.option("unet_transpose", 1), _lib.option("conv_split", 3):
-        assert _lib.get_option("unet_transpose") == 1 and _lib.get_option("conv_split") == 3
+    with _lib.option("unet_transpose", 1), _lib.option("conv_nm", 2):
+        assert _lib.get_option("unet_transpose") == 1 and _lib.get_option("conv_nm") == 2
+    # the split-bf16 modes were retired in round 5 (slower than exact f32 since the Winograd kernels): their switches are gone
+    for gone in ("conv_split", "attn_split"):
+        assert lib.ipdm_set_option(gone.encode(), 0) != 0 and b"unknown option" in lib.ipdm_last_error()
 
 
 def test_product_library_carries_only_the_default_path():
-    """The opt-in kernels (split-bf16 convolution / attention, the 16-cout MFMA form of the narrow layers) live in a second
-    shared object, libipdm_hip_optin.so, which the product library loads only when an opt-in option asks for them
-    (csrc/optin.hip): none of their device code is in libipdm_hip.so, and the second library exports what optin.hip binds."""
+    """The opt-in kernel (the 16-cout MFMA form of the narrow layers) lives in a second shared object, libipdm_hip_optin.so,
+    which the product library loads only when the option asks for it (csrc/optin.hip): none of its device code is in
+    libipdm_hip.so, the second library exports what optin.hip binds, and it reports which copy of the product it bound to."""
     import os
     from ipdm_pytorch_amd import _lib
     d = os.path.dirname(_lib.LIB_PATH)
@@ -113,11 +116,15 @@ def test_product_library_carries_only_the_default_path():
     optin_path = os.path.join(d, "libipdm_hip_optin.so")
     assert os.path.isfile(optin_path)
     optin = open(optin_path, "rb").read()
-    for kern in (b"conv_sx_kernel", b"conv_nm_kernel", b"attention_sx_kernel"):
+    for kern in (b"conv_nm_kernel",):
         assert kern not in prod and kern in optin, kern
+    for kern in (b"conv_sx_kernel", b"attention_sx_kernel"):      # retired in round 5
+        assert kern not in prod and kern not in optin, kern
     for kern in (b"conv_wino2_kernel", b"conv_ws_kernel", b"attention_ws_kernel", b"conv_direct"):
         assert kern in prod, kern
     h = C.CDLL(_lib.LIB_PATH) and C.CDLL(optin_path)      # (its undefined references resolve against the product library)
-    for sym in ("ipdm_optin_conv_sx_pack_weights", "ipdm_optin_conv2d_sx_launch", "ipdm_optin_conv_nm_eligible",
-                "ipdm_optin_conv2d_nm_launch", "ipdm_optin_attention_sx_scratch_floats", "ipdm_optin_attention_sx_launch"):
+    for sym in ("ipdm_optin_conv_nm_eligible", "ipdm_optin_conv2d_nm_launch", "ipdm_optin_bound_to"):
         assert getattr(h, sym) is not None
+    prod_h = C.CDLL(_lib.LIB_PATH)
+    h.ipdm_optin_bound_to.restype = C.c_void_p
+    assert h.ipdm_optin_bound_to() == C.cast(prod_h.ipdm_last_error, C.c_void_p).value      # the copy the process uses

@@ -426,23 +426,6 @@ def test_attention_key_slices_do_not_depend_on_the_schedule(T):
     assert (out[:1].cpu() - want).abs().max() <= 2e-5
 
 
-@pytest.mark.parametrize("B,heads,T", [(1, 4, 117), (2, 4, 1024), (1, 4, 1827), (1, 2, 4096)])
-def test_attention_kernel_split_bf16_x6(B, heads, T):
-    """attn_split = 3: both contractions as 3-piece split-bf16 (6 MFMA terms, f32 accumulate) at the SAME tolerance
-    as the exact-f32 kernel (ragged key blocks, several tiles, the rescale branch)."""
-    from ipdm_pytorch_amd import _lib
-    assert _lib.lib().ipdm_attention_kernel_code(64) == 1
-    with _lib.option("attn_split", 3):
-        assert _lib.lib().ipdm_attention_kernel_code(64) == 3       # the split kernel is what runs
-        test_attention_kernel(B, heads, T)
-
-
-def test_attention_random_lengths_split_bf16_x6():
-    from ipdm_pytorch_amd import _lib
-    with _lib.option("attn_split", 3):
-        test_attention_random_lengths()
-
-
 def test_attention_random_lengths():
     """Seeded random (B, heads, T): every ragged-tail length class of the 64-key tiles and 128/256-query workgroups."""
     from ipdm_pytorch_amd import _lib
@@ -590,8 +573,7 @@ def _conv_gn_conv(case):
     _lib.call("ipdm_op_conv_gn_conv", _lib.ptr(xd), C, B, H, W, _lib.ptr(arrs[0]), _lib.ptr(arrs[1]), CA, ksA, sA, _lib.ptr(rd),
               groups, _lib.ptr(arrs[2]), _lib.ptr(arrs[3]), act, _lib.ptr(arrs[4]), _lib.ptr(arrs[5]), CB, _lib.ptr(d_mid),
               _lib.ptr(d_out), ctypes.byref(rows), _lib.current_stream())
-    split_bf16 = _lib.lib().ipdm_conv_layout_code(CA, ksA, sA) >= 100  # (the opt-in split-bf16 kernels have no fused statistics)
-    assert rows.value > 0 or split_bf16, rows.value                    # every kernel family of the product path leaves fused statistics
+    assert rows.value > 0, rows.value                                  # every kernel family of the product path leaves fused statistics
     assert (d_mid.cpu() - mid).abs().max() <= 2e-5 * max(1.0, mid.abs().max().item())
     err = (d_out.cpu() - want).abs().max().item()
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
@@ -1014,7 +996,7 @@ def _up_conv_chain(case):
     _lib.call("ipdm_op_up_conv_chain", _lib.ptr(xd), C, B, Hs, Ws, _lib.ptr(arrs[0]), _lib.ptr(arrs[1]), CA, _lib.ptr(sd), C2,
               groups, _lib.ptr(arrs[2]), _lib.ptr(arrs[3]), act, _lib.ptr(arrs[4]), _lib.ptr(arrs[5]), CB, ksB, _lib.ptr(d_mid),
               _lib.ptr(d_out), ctypes.byref(used), _lib.current_stream())
-    wide_mfma = _lib.lib().ipdm_conv_layout_code(CA, 3, 1) in (2, 4)      # (not under the opt-in split-bf16 mode: its 3x3 form stays)
+    wide_mfma = _lib.lib().ipdm_conv_layout_code(CA, 3, 1) in (2, 4)
     assert used.value == (1 if wide_mfma else (2 if 4 < CA <= 16 else 0)), used.value
     assert (d_mid.cpu() - mid).abs().max() <= 2e-5 * max(1.0, mid.abs().max().item())
     err = (d_out.cpu() - want).abs().max().item()
@@ -1125,60 +1107,6 @@ def test_unet_small_golden(tag, golden):
     g = golden("unet_small")
     net, sd = _native_unet(SMALL_CFGS[tag], 11)
     assert list(net._shapes.keys()) == list(g[tag + "_keys"])
-    x = torch.from_numpy(synth.hash_normal(SMALL_SHAPES[tag], 101))
-    for t in (0, 7):
-        got = net(x.to(DEV), torch.full((1,), t, dtype=torch.long)).cpu().numpy()
-        np.testing.assert_allclose(got, g["%s_t%d" % (tag, t)], rtol=0, atol=1e-5)
-
-
-@pytest.fixture
-def split_bf16():
-    """Opt-in split-bf16 evaluation of the wide 3x3 convolutions (option conv_split, read when weights are packed)."""
-    from ipdm_pytorch_amd import _lib
-
-    def on(pieces):
-        _lib.set_option("conv_split", pieces)
-        assert _lib.lib().ipdm_conv_layout_code(64, 3, 1) == 100 + pieces      # the split kernel is what runs
-        assert _lib.lib().ipdm_conv_layout_code(64, 3, 2) in (2, 4) and _lib.lib().ipdm_conv_layout_code(16, 3, 1) == 0
-    yield on
-    _lib.set_option("conv_split", 0)
-
-
-@pytest.mark.parametrize("case", [
-    (2, 64, 0, 32, 32, 32, 32, 64, 3, 1, 2, True),
-    (1, 128, 64, 16, 32, 16, 32, 64, 3, 1, 2, False),
-    (1, 72, 0, 21, 35, 21, 35, 200, 3, 1, 2, True),         # ragged cin chunk and ragged cout tile
-    (1, 48, 0, 29, 63, 57, 125, 40, 3, 1, 0, False),        # up-sample, odd width (dword epilogue)
-    (1, 256, 0, 40, 48, 40, 48, 256, 3, 1, 2, True),
-])
-def test_conv_kernel_split_bf16_x6(case, split_bf16):
-    """3-piece split-bf16 (6 MFMA terms, f32 accumulate) meets the SAME tolerance as the exact-f32 kernel."""
-    split_bf16(3)
-    _conv_case(*case, seed=4200 + sum(case[:8]))
-
-
-def test_conv_kernel_random_shapes_split_bf16_x6(split_bf16):
-    """25 seeded random wide 3x3 stride-1 convolutions through the split-bf16 kernel (ragged cin chunks of 16, ragged
-    cout tiles, concat, up-sampling, W % 4 != 0, all prologues) at the exact-f32 kernel's tolerance."""
-    split_bf16(3)
-    rng = np.random.default_rng(771)
-    for i in range(25):
-        cout = int(rng.choice([40, 64, 96, 128, 200, 256]))
-        c1 = int(rng.choice([4, 16, 24, 64, 72, 128, 136, 256]))
-        c2 = int(rng.choice([0, 0, 16, 64])) if c1 % 32 == 0 else 0
-        act = int(rng.choice([0, 1, 2]))
-        B = int(rng.integers(1, 4))
-        Hs, Ws = int(rng.integers(5, 60)), int(rng.integers(5, 80))
-        up = rng.random() < 0.25
-        H, W = (Hs * 2 - int(rng.integers(0, 2)), Ws * 2 - int(rng.integers(0, 2))) if up else (Hs, Ws)
-        _conv_case(B, c1, c2, Hs, Ws, H, W, cout, 3, 1, act, bool(rng.random() < 0.5), seed=3000 + 13 * i)
-
-
-@pytest.mark.parametrize("tag", ["a", "b"])
-def test_unet_small_golden_split_bf16_x6(tag, golden, split_bf16):
-    split_bf16(3)
-    g = golden("unet_small")
-    net, sd = _native_unet(SMALL_CFGS[tag], 11)
     x = torch.from_numpy(synth.hash_normal(SMALL_SHAPES[tag], 101))
     for t in (0, 7):
         got = net(x.to(DEV), torch.full((1,), t, dtype=torch.long)).cpu().numpy()

@@ -43,7 +43,7 @@ def main(fetch_db, write_db, tag):
     src = "conv_wino2.hip" if any("conv_wino2_kernel" in k for k in dom) else ("conv_wino.hip" if any("conv_wino_kernel" in k for k in dom) else "conv_ws.hip")
     with open(os.path.join(ROOT, "ipdm-pytorch_amd", "csrc", src), "rb") as fh:
         sha = hashlib.sha256(fh.read()).hexdigest()[:16]
-    mode = {"3": "split-bf16-x6", "2": "split-bf16-x3"}.get(os.environ.get("IPDM_CONV_SPLIT", ""), "exact-f32")
+    mode = "exact-f32"
     if os.environ.get("IPDM_CONV_NO_WINO"):
         mode += "-nowino"
     d = {"tag": tag, "kernel": {"conv_wino2.hip": "conv_wino2_kernel (wide 3x3 stride-1, Winograd domain, 128-cout tiles)",
