@@ -39,6 +39,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef IPDM_PW_SAFE_WAIT
+#define IPDM_PW_SAFE_WAIT 0         // 1: every wait for a ring slot drains the whole queue (s_waitcnt vmcnt(0)) instead of the hand-counted
+#endif                              // vmcnt(N): `make pwsafe` builds libipdm_hip_pwsafe.so with it, and a GPU test holds the shipped kernel's bits
+                                    // to that build's (tests/test_gpu_parity.py::test_pointwise_ring_waits_equal_a_full_drain)
 #ifndef IPDM_PW_KO
 #define IPDM_PW_KO 0                // compile-time timing knock-out (tools/build_variants.sh; WRONG results): 1 = no operand loads after the
 #endif                              // prologue.  (Skipping the epilogue is not a valid knock-out: the MFMAs become dead code.)
@@ -84,12 +88,12 @@ __device__ inline void ring_load_w(f32x4 &w, int w_v, i32x4 w_rsrc, int w_s)
 template <int N>
 __device__ inline void ring_wait(float (&x)[1], f32x4 &w)
 {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x[0]), "+v"(w) : "n"(N));
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x[0]), "+v"(w) : "n"(IPDM_PW_SAFE_WAIT ? 0 : N));
 }
 template <int N>
 __device__ inline void ring_wait(float (&x)[2], f32x4 &w)
 {
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(x[0]), "+v"(x[1]), "+v"(w) : "n"(N));
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(x[0]), "+v"(x[1]), "+v"(w) : "n"(IPDM_PW_SAFE_WAIT ? 0 : N));
 }
 
 struct Item { int n, p0, co0; };
@@ -239,8 +243,13 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
         const size_t sample = (size_t)cur.n * a.Cout * HW;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + sample), 0, a.Cout * plane_bytes, 0x00020000);
         // (no residual: zero records -- the loads return 0 and the add stays unconditional)
-        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((a.res ? a.res : a.out) + sample), 0,
-                                                                                   a.res ? a.Cout * plane_bytes : 0, 0x00020000);
+        // (the GroupNorm instantiations -- the qkv projections -- have no residual path: no layer of the reference normalises the
+        //  input of a 1x1 AND adds a residual, conv_pw_layer_ok refuses such a layer, and the 32 registers of the residual
+        //  prefetch were what made the ACT / 64-pixel instantiations spill next to the register ring: ADVICE r04.  The Makefile
+        //  refuses a build in which any instantiation of this kernel spills a vector register)
+        const bool has_res = !ACT && a.res;
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((has_res ? a.res : a.out) + sample), 0,
+                                                                                   has_res ? a.Cout * plane_bytes : 0, 0x00020000);
         // a 32-pixel block x 32-cout block of the item: + residual, 16-byte stores, the block's statistics row
         auto block = [&](int pb, int b, const f32x4 (&r)[4]) __attribute__((always_inline)) {
             const int so = ((cur.co0 + 32 * b) * HW + cur.p0 + 32 * pb) * 4;
@@ -267,7 +276,7 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
             for (int i = 0; i < 16; ++i) {
                 const int px = 8 * (i >> 2) + 4 * lk + (i & 3);
                 const int off = px < nv ? vo + (i >> 2) * 32 + (i & 3) * 4 : OOB;
-                const float v = acc[pb][b][i] + bload(r_rsrc, off, so);
+                const float v = ACT ? acc[pb][b][i] : acc[pb][b][i] + bload(r_rsrc, off, so);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, off, so, 0);
                 const float vm = px < nv ? v : 0.0f;
                 s1 += vm; s2 = __builtin_fmaf(vm, vm, s2);
@@ -282,7 +291,7 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
         if (HW - cur.p0 >= BP) {
             // (a wait for a residual load also waits for every store issued before it: the loads run one block ahead of the
             //  stores, and a layer without a residual issues none)
-            if (a.res) {
+            if (has_res) {
                 f32x4 r[2][4];
                 auto fetch = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
@@ -308,9 +317,11 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
                 if (nv >= 32) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        f32x4 r[4];
+                        f32x4 r[4] = {};
+                        if (!ACT) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) r[q] = bload4(r_rsrc, vo, ((cur.co0 + 32 * b) * HW + cur.p0 + 32 * pb) * 4 + q * 32);
+                            for (int q = 0; q < 4; ++q) r[q] = bload4(r_rsrc, vo, ((cur.co0 + 32 * b) * HW + cur.p0 + 32 * pb) * 4 + q * 32);
+                        }
                         if (pb == 0) block(0, b, r); else block(NPB - 1, b, r);
                     }
                 } else {
@@ -336,7 +347,7 @@ bool conv_pw_layer_ok(const ConvArgs &a)
     const int Ctot = a.C1 + a.C2;
     if (a.ksize != 1 || a.stride != 1 || a.w_interleave != 4 || a.Cout % BN || a.cout_pad != a.Cout) return false;
     if (a.upsample || a.H != a.Hs || a.W != a.Ws || a.Ho != a.H || a.Wo != a.W) return false;
-    if (Ctot % KC_MIN || Ctot < 2 * KC_MIN || (a.C2 && a.C1 % KC_MIN) || a.act == 2 || a.sk_w) return false;
+    if (Ctot % KC_MIN || Ctot < 2 * KC_MIN || (a.C2 && a.C1 % KC_MIN) || a.act == 2 || a.sk_w || (a.act && a.res)) return false;
     if ((long)(a.C1 > a.C2 ? a.C1 : a.C2) * a.Ho * a.Wo >= (1L << 29) || (long)a.Cout * a.Ho * a.Wo >= (1L << 29)) return false;
     return conv_ws_split(a) == 1;
 }

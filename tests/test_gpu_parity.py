@@ -697,20 +697,44 @@ def test_wino128_fused_statistics_and_planar_reader():
                 test_upsample_conv_parity_form(case)
 
 
+def _conv3x3_repeats(B, C1, C2, H, W, Cout, act, res, reps, seed=5):
+    """One wide 3x3 layer `reps` + 1 times through conv_wino2: how many runs differ from the first; the first run; the 64-cout
+    kernel's result (wino_v1) when the 128-cout kernel took the launch."""
+    from ipdm_pytorch_amd import _lib
+    Cin = C1 + C2
+    x1 = torch.from_numpy(synth.hash_normal((B, C1, H, W), seed)).to(DEV)
+    x2 = torch.from_numpy(synth.hash_normal((B, C2, H, W), seed + 1)).to(DEV) if C2 else None
+    rd = torch.from_numpy(synth.hash_normal((B, Cout, H, W), seed + 6)).to(DEV) if res else None
+    wn, bn, gn_, ben = (np.ascontiguousarray(t, dtype=np.float32) for t in (
+        synth.hash_normal((Cout, Cin, 3, 3), seed + 2) / np.sqrt(Cin * 9), synth.hash_normal((Cout,), seed + 3),
+        synth.hash_uniform((Cin,), seed + 4) + 0.5, synth.hash_normal((Cin,), seed + 5) * 0.2))
+
+    def once():
+        out = torch.full((B, Cout, H, W), float("nan"), device=DEV)
+        _lib.call("ipdm_op_conv2d", _lib.ptr(x1), C1, _lib.ptr(x2), C2, B, H, W, H, W, _lib.ptr(wn), _lib.ptr(bn), Cout, 3, 1,
+                  act, ou.gn_groups(Cin), _lib.ptr(gn_), _lib.ptr(ben), _lib.ptr(rd), _lib.ptr(out), _lib.current_stream())
+        return out
+    with _lib.option("wino2_min_tiles", 1):
+        code = _lib.lib().ipdm_conv_kernel_code(B, Cout, Cin, 3, 1, H, W)
+        first = once()
+        assert bool(torch.isfinite(first).all())
+        bad = sum(int(not torch.equal(once(), first)) for _ in range(reps))
+    ref = None
+    if code == 2:
+        with _lib.option("wino_v1", 1):
+            ref = once()
+    return bad, first, ref
+
+
 def test_wino2_run_to_run_determinism():
-    """conv_wino2 under repetition (tools/wino_stress.py with fewer rounds): launches with one tile per workgroup (waves end
-    right behind their last stores), many-round launches, K slices, odd sizes -- every run bit-equal to the first and to the
-    64-cout kernel.  (The shelved 1x1 experiment on the same structure, tools/experiments/conv_pw.hip, failed exactly this.)"""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("wino_stress", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                              "tools", "wino_stress.py"))
-    ws = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(ws)
-    bad = 0
+    """conv_wino2 under repetition: launches with one tile per workgroup (waves end right behind their last stores), many-round
+    launches, K slices, odd sizes -- every run bit-equal to the first and to the 64-cout kernel.  (The shelved 1x1 experiment
+    on the same structure, tools/experiments/conv_pw.hip, failed exactly this.)"""
     for case in [(1, 128, 0, 72, 64, 128, 2, True), (2, 128, 0, 100, 96, 256, 2, False), (1, 256, 0, 32, 32, 256, 2, True),
                  (1, 128, 16, 61, 129, 128, 1, True)]:
-        bad += ws.stress(*case, reps=12)
-    assert bad == 0
+        bad, first, ref = _conv3x3_repeats(*case, reps=12)
+        assert bad == 0, case
+        assert ref is None or torch.equal(ref, first), case
 
 
 PW_CASES = [
@@ -769,6 +793,84 @@ def test_pointwise_kernel_statistics_and_planar_reader_equal_the_staged_kernel()
         _pw_chains()
     finally:
         _lib.set_option("pw_force", 0)
+
+
+def _pw_inputs(case):
+    B, C1, C2, H, W, Cout, act, res = case
+    seed = 9100 + sum(case[:6])
+    d = dict(x=(torch.from_numpy(synth.hash_normal((B, C1, H, W), seed)) * 1.4 + 0.3).to(DEV),
+             x2=(torch.from_numpy(synth.hash_normal((B, C2, H, W), seed + 1)) * 0.8).to(DEV) if C2 else None,
+             w=np.ascontiguousarray(synth.hash_normal((Cout, C1 + C2, 1, 1), seed + 2) / np.sqrt(C1 + C2), dtype=np.float32),
+             b=np.ascontiguousarray(synth.hash_normal((Cout,), seed + 3), dtype=np.float32),
+             gamma=np.ascontiguousarray(synth.hash_uniform((C1 + C2,), seed + 4) + 0.5, dtype=np.float32) if act else None,
+             beta=np.ascontiguousarray(synth.hash_normal((C1 + C2,), seed + 5) * 0.2, dtype=np.float32) if act else None,
+             r=torch.from_numpy(synth.hash_normal((B, Cout, H, W), seed + 6)).to(DEV) if res else None)
+    return d
+
+
+def _pw_run(handle, case, d):
+    """ipdm_op_conv2d of a 1x1 layer through the C ABI of `handle` (the product library or a variant build of it)."""
+    from ipdm_pytorch_amd import _lib
+    B, C1, C2, H, W, Cout, act, res = case
+    out = torch.full((B, Cout, H, W), float("nan"), device=DEV)
+    rc = handle.ipdm_op_conv2d(_lib.ptr(d["x"]), C1, _lib.ptr(d["x2"]), C2, B, H, W, H, W, _lib.ptr(d["w"]), _lib.ptr(d["b"]), Cout, 1, 1,
+                               act, ou.gn_groups(C1 + C2) if act else 0, _lib.ptr(d["gamma"]), _lib.ptr(d["beta"]), _lib.ptr(d["r"]),
+                               _lib.ptr(out), _lib.current_stream())
+    assert rc == 0, handle.ipdm_last_error()
+    return out
+
+
+# the table is rewritten when a wave's sample changes (three samples, 12 items per sample and cout tile: waves cross samples
+# mid-stream); a ragged last item (41 x 67 = 2747 pixels); several items per wave; both sources of a concat
+PW_STRESS_CASES = [(3, 96, 32, 41, 67, 128, 1, False), (2, 256, 0, 57, 125, 768, 1, False), (2, 256, 0, 57, 125, 256, 0, True),
+                   (1, 128, 128, 96, 96, 128, 0, True)]
+
+
+def test_pointwise_kernel_under_repetition():
+    """the shipped pointwise kernel keeps both MFMA operands in a register ring that inline asm loads and
+    hand-counted s_waitcnt vmcnt(N) wait for -- an idiom whose shelved first version (tools/experiments/conv_pw.hip) produced a
+    run-dependent handful of wrong zeros.  200 launches per case and item shape (GroupNorm table rewritten mid-wave, ragged
+    last item, residual, concat): every output equals the first bit for bit, and the first equals the staged kernel's."""
+    from ipdm_pytorch_amd import _lib
+    h = _lib.lib()
+    for case in PW_STRESS_CASES:
+        d = _pw_inputs(case)
+        with _lib.option("conv_no_pw", 1):
+            staged = _pw_run(h, case, d)
+        assert bool(torch.isfinite(staged).all())
+        with _lib.option("pw_force", 1):
+            assert h.ipdm_conv_kernel_code(case[0], case[5], case[1] + case[2], 1, 1, case[3], case[4]) == 10
+            for item in (1, 2):
+                with _lib.option("pw_item", item):
+                    bad = sum(int(not torch.equal(_pw_run(h, case, d), staged)) for _ in range(100))
+                assert bad == 0, (case, item, bad)
+
+
+def test_pointwise_ring_waits_equal_a_full_drain():
+    """... and against a build of the SAME kernel in which every ring wait drains the whole queue (libipdm_hip_pwsafe.so:
+    conv_pw.hip with -DIPDM_PW_SAFE_WAIT, `make pwsafe`, built by __graft_entry__.build()): a hand-counted wait that is one
+    too loose shows as a difference between the two builds; a toolchain bump cannot pass silently."""
+    import ctypes as C
+    from ipdm_pytorch_amd import _lib
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libipdm_hip_pwsafe.so")
+    assert os.path.isfile(path), "libipdm_hip_pwsafe.so missing: run __graft_entry__.build()"
+    safe = C.CDLL(path)
+    for name in ("ipdm_op_conv2d", "ipdm_set_option", "ipdm_conv_kernel_code"):
+        getattr(safe, name).restype, getattr(safe, name).argtypes = _lib.PROTOTYPES[name]
+    safe.ipdm_last_error.restype = C.c_char_p
+    assert safe.ipdm_set_option(b"pw_force", 1) == 0
+    h = _lib.lib()
+    with _lib.option("pw_force", 1):
+        for case in PW_STRESS_CASES + [PW_CASES[4], PW_CASES[5]]:
+            d = _pw_inputs(case)
+            assert safe.ipdm_conv_kernel_code(case[0], case[5], case[1] + case[2], 1, 1, case[3], case[4]) == 10
+            for item in (1, 2):
+                assert safe.ipdm_set_option(b"pw_item", item) == 0
+                want = _pw_run(safe, case, d)
+                with _lib.option("pw_item", item):
+                    for rep in range(10):
+                        got = _pw_run(h, case, d)
+                        assert torch.equal(got, want), (case, item, rep, int((got != want).sum()))
 
 
 def _pw_chains():
