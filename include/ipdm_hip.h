@@ -296,6 +296,10 @@ int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
  *   -1 = bad argument.
  * Test aid (replaces nothing in the reference): a parity test asserts the kernel it believes it covers. */
 int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W);
+/* ... the same for a layer whose output feeds a GroupNorm (the executor asks such a layer for fused statistics, and the
+ * kernel rule of a statistics-producing layer looks at the layer alone, never at the batch): e.g. a wide 1x1 layer is 10
+ * (conv_pw) here only if ONE sample brings >= 1024 items, whatever B. */
+int32_t ipdm_conv_kernel_code_stats(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W);
 /* Which attention kernel a launch with head dim d takes NOW: 0 = 4-wave kernel (d = 32, or IPDM_ATTN_LEGACY),
  * 1 = wave-specialised exact-f32 MFMA (the default for d = 64). */
 int32_t ipdm_attention_kernel_code(int32_t d);

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "ipdm_op_attention": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ipdm_conv_layout_code": (_i32, [_i32, _i32, _i32]),
     "ipdm_conv_kernel_code": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "ipdm_conv_kernel_code_stats": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "ipdm_attention_kernel_code": (_i32, [_i32]),
     "ipdm_art_plan_create": (C.c_int, [_vp, _vp, _vp, C.POINTER(_vp)]),
     "ipdm_art_plan_destroy": (C.c_int, [_vp]),

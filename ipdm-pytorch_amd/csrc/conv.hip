@@ -450,7 +450,8 @@ void conv_pack_weights_up2(const float *w, int Cout, int Cin, int interleave, st
 bool conv_planar_ok(const ConvArgs &a)
 {
     if (a.upsample || (a.Hs & 1) || (a.Ws & 1)) return false;
-    if (a.w_interleave && conv_pw_layer_ok(a)) return true;            // (either kernel such a layer can land on reads parity-planar x1)
+    // (a layer of the pointwise kernel may still land on conv_ws.hip -- a low-fill launch without fused statistics -- so the
+    //  producer's layout decision follows the STRICTER reader: conv_ws_planar_ok; conv_pw itself only needs even Ho / Wo)
     if (a.w_interleave) return conv_ws_planar_ok(a);                    // the wave-specialised kernels (conv_ws.hip)
     // (the stride-2 direct kernel and the 4-wave kernels below read NCHW only)
     return a.stride == 1 && !opt(OPT_CONV_NO_DIRECT) && !opt(OPT_DIRECT_NO_PLANAR) && conv_direct_eligible(a);

@@ -1375,7 +1375,18 @@ extern "C" int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t st
     return conv_weight_interleave(Cout, ksize, stride);
 }
 
+static int32_t conv_kernel_code_impl(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W, bool with_stats);
 extern "C" int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W)
+{
+    return conv_kernel_code_impl(B, Cout, Cin, ksize, stride, H, W, false);
+}
+// ... for a layer whose output feeds a GroupNorm (the executor asks it for fused statistics): the kernel rule of such a layer
+// looks at the layer alone, never at the batch (conv_pw_stats_layer), so the answer can differ from the plain query's
+extern "C" int32_t ipdm_conv_kernel_code_stats(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W)
+{
+    return conv_kernel_code_impl(B, Cout, Cin, ksize, stride, H, W, true);
+}
+static int32_t conv_kernel_code_impl(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W, bool with_stats)
 {
     if (B <= 0 || Cout <= 0 || Cin <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3) || stride < 1 || stride > 2) return -1;
     static float dummy;                    // (only tested for null by the eligibility rules)
@@ -1391,6 +1402,7 @@ extern "C" int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, i
     a.tiles_x = a.tiles_y = a.co_tiles = 0;
     a.w_wino = conv_wino_shape_ok(Cout, Cin, ksize, stride, a.w_interleave) ? &dummy : nullptr;
     a.split_ws = &dummy;
+    if (with_stats) { a.stats = &dummy; a.stats_rows = conv_stats_rows(a); }
     return conv_kernel_code(a);
 }
 

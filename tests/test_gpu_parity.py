@@ -622,6 +622,13 @@ def test_conv_kernel_code_table():
     with _lib.option("pw_force", 1):
         assert code(1, 768, 256, 1, 1, 57, 125) == 10
     assert code(0, 128, 128, 3, 1, 8, 8) == -1
+    # a layer that leaves fused statistics (its output feeds a GroupNorm) takes its kernel by a rule of the layer ALONE: the
+    # plain query above answers by the batch's fill, the statistics query must not (the test aid mirrors the rule)
+    scode = _lib.lib().ipdm_conv_kernel_code_stats
+    assert code(8, 256, 256, 1, 1, 57, 125) == 10 and scode(8, 256, 256, 1, 1, 57, 125) == 3      # proj_out @57x125: 446 items per sample
+    assert scode(1, 256, 256, 1, 1, 57, 125) == 3
+    assert scode(1, 128, 256, 1, 1, 228, 500) == 10 and scode(8, 128, 256, 1, 1, 228, 500) == 10  # 3563 items per sample: either batch
+    assert scode(8, 128, 128, 3, 1, 512, 512) == 2 and scode(8, 8, 8, 3, 1, 2000, 912) == 5        # (other families: as the plain query)
 
 
 WINO128_CASES = [
@@ -1383,83 +1390,86 @@ def test_smoke_pipeline_matches_oracle_psnr():
 def test_smoke_pipeline_fp64_arbiter():
     """Who is right when two float32 evaluations differ?  The reduced end-to-end pipeline once more on the CPU in FLOAT64
     (same float32 inputs, weights, draws and schedule constants: oracle.pipeline.progressive_slice on float64 tensors) is
-    the value both approximate.  STAGE BY STAGE for the canonical seed -- every stored iterate of the projection loop, the FBP
-    image, every iterate of the image loops: up to the first amplifying pass both evaluations sit at 1e-7 of the arbiter and
-    the comparison is sharp (HIP at most 1.5x as far as the float32 CPU oracle, rms and max-abs).  One image-domain pass of
-    these random-weight networks then amplifies rounding ~100x, chaotically (round 3: the oracle's own distance moved 2.4x
-    with nothing but its thread count); after it this single sample only has to stay under the hard caps, and the criterion
-    is the median over seeds of test_smoke_pipeline_fp64_arbiter_over_seeds."""
+    the value both approximate.  STAGE BY STAGE -- every stored iterate of the projection loop, the FBP image, every iterate of
+    the image loops -- for THREE seeds (weights, phantom, dose noise, draws all vary).  Up to the first amplifying pass both
+    evaluations sit at 1e-7 of the arbiter and the comparison is sharp for every seed (HIP at most 1.5x as far as the float32
+    CPU oracle, rms and max-abs).  One image-domain pass of these random-weight networks then amplifies rounding ~100x,
+    chaotically (round 3: the oracle's own distance moved 2.4x with nothing but its thread count): after it a single seed is
+    one draw from that distribution, so each amplified stage is judged by the MEDIAN over the seeds (ARBITER_MEDIAN_*, the
+    criterion of test_smoke_pipeline_fp64_arbiter_over_seeds) plus the hard cap on the worst one."""
     from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
     from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG, _RecordingNoise
     from ipdm_pytorch_amd.diffusion import NoiseSource
     from ipdm_pytorch_amd.unet import UNetModel
     from oracle import pipeline as op
-    opt = default_cfg([])
-    cfg_load(mayo_test_options(), opt.__dict__)
-    cfg_load(dict(device=DEV, t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=True, save_it_state_proj=True,
-                  save_it_state_img=True), opt.__dict__)
-    den = progressive_domain_denoiser(opt, seed=11)
-    den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
-    den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
-    sd_p = synth.synth_state_dict(den.proj_model._shapes, seed=21)
-    sd_i = synth.synth_state_dict(den.img_model._shapes, seed=22)
-    den.proj_model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_p.items()})
-    den.img_model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_i.items()})
-    sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(1)), seed=1)
-    den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
-    rec = _RecordingNoise(NoiseSource(11, 0))
-    den.noise = rec
-    den.progressive_denoiser(save_proj_state=True, sharpen_num=70)
-    draws = [z.cpu() for z in rec.draws]
     cfg_p = ou.UNetConfig(1, 16, 1, attention_resolutions=(16,), channel_mult=(0.25, 0.25, 0.5, 1, 2, 4), num_heads=1)
     cfg_i = ou.UNetConfig(1, 16, 1, attention_resolutions=(8,), channel_mult=(1, 1, 2, 2, 4), num_heads=1)
-
-    def oracle(dt, threads):
-        torch.set_num_threads(min(threads, os.cpu_count() or threads))
-        it = iter(draws)
-        _, mid = op.progressive_slice(dict(opt.__dict__), cfg_p, {k: torch.from_numpy(v).to(dt) for k, v in sd_p.items()}, cfg_i,
-                                      {k: torch.from_numpy(v).to(dt) for k, v in sd_i.items()},
-                                      torch.from_numpy(sino)[None, None].to(dt), lambda: next(it).to(dt), sharpen_num=70)
-        return ([m.numpy() for m in mid["proj"]], mid["fbp"].numpy(), [m.numpy() for m in mid["img"]])
-    m64 = oracle(torch.float64, 64)
-    m32 = [oracle(torch.float32, nt) for nt in (32,)]      # (round 3 ran 16 / 32 / 64 threads here to show that the oracle's own distance
-                                                                # moves 2.4x with its thread count; the statistic over seeds replaced that)
-    n_p, n_i = len(m64[0]), len(m64[2])
-    hip = ([den.proj_denoise_result[k + 1] for k in range(n_p)], den.proj_denoise_convert2img_result[n_p],
-           [den.progressive_denoise_result[k + 1] for k in range(n_i)])
 
     def dist(a, b):
         e = np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))
         return float(e.max()), float(np.sqrt((e ** 2).mean()))
-    stages = [("proj iter_%d" % (k + 1), lambda m, k=k: m[0][k]) for k in range(n_p)] + [("fbp", lambda m: m[1])] + \
-             [("img iter_%d" % (k + 1), lambda m, k=k: m[2][k]) for k in range(n_i)]
-    worst = 0.0
-    for name, pick in stages:
-        h = dist(pick(hip), pick(m64))
-        cs = [dist(pick(m), pick(m64)) for m in m32]
-        c = (max(x[0] for x in cs), max(x[1] for x in cs))
-        print("fp64 arbiter %-11s |hip-f64| max %.3e rms %.3e | |cpu32-f64| max %s rms %s | ratio max %.2f rms %.2f"
-              % (name, h[0], h[1], ["%.2e" % x[0] for x in cs], ["%.2e" % x[1] for x in cs], h[0] / c[0], h[1] / c[1]))
-        worst = max(worst, h[0] / c[0], h[1] / c[1])
-        # Up to the amplifying pass (both evaluations at 1e-7 of the arbiter) the comparison is sharp: 1.5x in rms and max-abs.
-        # After it one seed is one sample of a chaotic amplification (the three oracle variants alone spread 2.5-3x in
-        # max-abs): there the criterion is the MEDIAN over seeds of test_smoke_pipeline_fp64_arbiter_over_seeds
-        # (ARBITER_MEDIAN_*); this single sample only has to stay under the hard caps.
-        amplified = c[1] > 1e-6
-        if amplified:
-            assert h[1] <= ARBITER_WORST_RMS * c[1] and h[0] <= ARBITER_WORST_MAX * c[0], (name, h, cs)
-        else:
-            assert h[1] <= 1.5 * c[1] and h[0] <= 1.5 * c[0], (name, h, cs)
-    # float32 vs float32 at the end of the chain: bounded by what the arbiter justifies (the sum of the two distances)
-    ff = dist(hip[2][-1], m32[0][2][-1])
-    scale = float(np.abs(m64[2][-1]).max())
-    print("fp64 arbiter: worst stage ratio %.2f; |hip-cpu32(32 threads)| at the end max %.3e rms %.3e (scale %.3f)" % (worst, ff[0], ff[1], scale))
-    assert ff[0] <= E2E_MAX_REL * max(1.0, scale)
+    per_stage = {}                       # stage -> [(ratio max-abs, ratio rms, amplified)] over the seeds
+    for k, (seed, wp, wi, ph) in enumerate(((11, 21, 22, 1), (29, 102, 103, 2), (43, 104, 105, 3))):
+        opt = default_cfg([])
+        cfg_load(mayo_test_options(), opt.__dict__)
+        cfg_load(dict(device=DEV, t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=True, save_it_state_proj=True,
+                      save_it_state_img=True), opt.__dict__)
+        den = progressive_domain_denoiser(opt, seed=seed)
+        den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
+        den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
+        sd_p = synth.synth_state_dict(den.proj_model._shapes, seed=wp)
+        sd_i = synth.synth_state_dict(den.img_model._shapes, seed=wi)
+        den.proj_model.load_state_dict({n: torch.from_numpy(v) for n, v in sd_p.items()})
+        den.img_model.load_state_dict({n: torch.from_numpy(v) for n, v in sd_i.items()})
+        sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(ph)), seed=ph)
+        den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
+        rec = _RecordingNoise(NoiseSource(seed, 0))
+        den.noise = rec
+        den.progressive_denoiser(save_proj_state=True, sharpen_num=70)
+        draws = [z.cpu() for z in rec.draws]
+
+        def oracle(dt, threads):
+            torch.set_num_threads(min(threads, os.cpu_count() or threads))
+            it = iter(draws)
+            _, mid = op.progressive_slice(dict(opt.__dict__), cfg_p, {n: torch.from_numpy(v).to(dt) for n, v in sd_p.items()}, cfg_i,
+                                          {n: torch.from_numpy(v).to(dt) for n, v in sd_i.items()},
+                                          torch.from_numpy(sino)[None, None].to(dt), lambda: next(it).to(dt), sharpen_num=70)
+            return ([m.numpy() for m in mid["proj"]], mid["fbp"].numpy(), [m.numpy() for m in mid["img"]])
+        m64 = oracle(torch.float64, 64)
+        m32 = oracle(torch.float32, 32)
+        n_p, n_i = len(m64[0]), len(m64[2])
+        hip = ([den.proj_denoise_result[j + 1] for j in range(n_p)], den.proj_denoise_convert2img_result[n_p],
+               [den.progressive_denoise_result[j + 1] for j in range(n_i)])
+        stages = [("proj iter_%d" % (j + 1), lambda m, j=j: m[0][j]) for j in range(n_p)] + [("fbp", lambda m: m[1])] + \
+                 [("img iter_%d" % (j + 1), lambda m, j=j: m[2][j]) for j in range(n_i)]
+        for name, pick in stages:
+            h, c = dist(pick(hip), pick(m64)), dist(pick(m32), pick(m64))
+            amplified = c[1] > 1e-6
+            print("fp64 arbiter seed %d %-11s |hip-f64| max %.3e rms %.3e | |cpu32-f64| max %.3e rms %.3e | ratio max %.2f rms %.2f%s"
+                  % (seed, name, h[0], h[1], c[0], c[1], h[0] / c[0], h[1] / c[1], "  (amplified)" if amplified else ""))
+            per_stage.setdefault(name, []).append((h[0] / c[0], h[1] / c[1], amplified))
+            if not amplified:            # sharp, seed by seed
+                assert h[1] <= 1.5 * c[1] and h[0] <= 1.5 * c[0], (seed, name, h, c)
+            else:
+                assert h[1] <= ARBITER_WORST_RMS * c[1] and h[0] <= ARBITER_WORST_MAX * c[0], (seed, name, h, c)
+        # float32 vs float32 at the end of the chain: bounded by what the arbiter justifies (the sum of the two distances).  The
+        # frozen bound is the canonical seed's; other weight seeds of the reduced networks are judged by the arbiter only.
+        if k == 0:
+            ff = dist(hip[2][-1], m32[2][-1])
+            scale = float(np.abs(m64[2][-1]).max())
+            print("fp64 arbiter: |hip-cpu32(32 threads)| at the end max %.3e rms %.3e (scale %.3f)" % (ff[0], ff[1], scale))
+            assert ff[0] <= E2E_MAX_REL * max(1.0, scale)
+    for name, rs in per_stage.items():
+        amp = [r for r in rs if r[2]]
+        if len(amp) >= 2:                # the stages behind the amplifying pass: the median over the seeds is the measurement
+            med_max, med_rms = float(np.median([r[0] for r in amp])), float(np.median([r[1] for r in amp]))
+            print("fp64 arbiter %-11s median over %d seeds: max-abs ratio %.2f rms ratio %.2f" % (name, len(amp), med_max, med_rms))
+            assert med_rms <= ARBITER_MEDIAN_RMS and med_max <= ARBITER_MEDIAN_MAX, (name, rs)
 
 
 def test_smoke_pipeline_fp64_arbiter_over_seeds(tmp_path):
     """The fp64 arbiter as a statistic: the reduced end-to-end pipeline (proj loop 2+2 steps, FBP, sharpen, img loop, ultra
-    pass) for FIVE seeds -- network weights, phantom, dose noise and diffusion draws all vary -- each replayed by the CPU
+    pass) for SEVEN seeds -- network weights, phantom, dose noise and diffusion draws all vary -- each replayed by the CPU
     oracle in float32 and in float64 (pinned child processes).  Median over the seeds of err(HIP, fp64) / err(oracle32,
     fp64) at the END of the chain (after the amplifying image-domain passes): <= 1.25 in rms, <= 1.5 in max-abs."""
     from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
@@ -1468,7 +1478,7 @@ def test_smoke_pipeline_fp64_arbiter_over_seeds(tmp_path):
     from ipdm_pytorch_amd.unet import UNetModel
     from tests import _oracle_child as oc
     hips, jobs32, jobs64 = [], [], []
-    for k, seed in enumerate((11, 29, 43, 61, 83)):
+    for k, seed in enumerate((11, 29, 43, 61, 83, 97, 113)):      # (round 5: two more -- a median of 1.32 under 1.5 on five was thin)
         opt = default_cfg([])
         cfg_load(mayo_test_options(), opt.__dict__)
         cfg_load(dict(device=DEV, t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=True), opt.__dict__)
@@ -1742,11 +1752,12 @@ def _check_full_size(got, want, phantom, max_rel):
 
 ARBITER_MEDIAN_RMS, ARBITER_MEDIAN_MAX = 1.25, 1.5       # median over the seeds of err(HIP, fp64) / err(oracle32, fp64)
 # Hard caps on the worst seed.  Measured (round 4, gpurun_out/arbiter_*.txt): full size -- the production kernels -- rms
-# ratios 0.98 ... 1.02, max-abs 0.93 ... 1.10 (nothing amplifies there: both evaluations end 1.3e-7 rms from the arbiter).  The
+# ratios 0.99 ... 1.03, max-abs 0.93 ... 1.24 (nothing amplifies there: both evaluations end 1.3e-7 rms from the arbiter).  The
 # reduced random-weight networks amplify rounding chaotically: over five weight seeds the float32 ORACLE's own distance to the
 # arbiter spans 1.9e-7 ... 4.3e-4 rms, and the ratio of two such samples 0.86 ... 2.16 (rms), 0.75 ... 2.48 (max-abs) around
-# a median of 1.00 / 1.32 -- a single seed's ratio is noise, the median is the measurement.
-ARBITER_WORST_RMS, ARBITER_WORST_MAX = 4.0, 4.0
+# a median of 1.00 / 1.32 -- a single seed's ratio is noise, the median is the measurement.  Round 5: caps 4 -> 3 (the measured
+# worst is 2.48), seven seeds in the reduced statistic, the stage-by-stage test judged by its median behind the amplifying pass.
+ARBITER_WORST_RMS, ARBITER_WORST_MAX = 3.0, 3.0
 
 
 def _arbiter_ratios(tag, hips, c32s, f64s):
