@@ -464,7 +464,7 @@ def main():
                 "b8_s_per_slice": round(per8, 4), "ratio_to_b8": round(min(dt1, dtg) / per8, 3),
                 "note": "one slice alone through the same pipeline (warm-up + 1 timed pass), launches issued one by one / UNet "
                         "forwards replayed from hipGraphs; the gap to B=8 is chip under-fill of the low-resolution layers "
-                        "(DESIGN 6e)"}
+                        "(NOTEBOOK.md, B = 1 latency)"}
             # ---- the DROP-IN call: the reference-shaped progressive_denoiser() (Utils/train_test_utils.py:552-567) on the
             # same B slices -- result dictionaries on the host, the FBP image through the host, as a caller of the
             # reference's surface gets it; the headline times the device-resident form of the same arithmetic

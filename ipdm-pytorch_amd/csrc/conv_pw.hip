@@ -6,7 +6,7 @@
 // Why a kernel of its own.  conv_ws.hip runs these layers through its producer/consumer structure (LDS stage, one hand-over
 // barrier per 32-channel chunk) at 0.4-0.6 of the f32 MFMA peak, and the first attempt at a pointwise kernel
 // (tools/experiments/conv_pw.hip: the conv_wino2 recipe, LDS-staged pixels, one barrier per chunk) did not beat it: what
-// those structures lose is the hand-over, not issue slots.  A pointwise operator needs no hand-over at
+// those structures lose is the hand-over, not issue slots (NOTEBOOK.md).  A pointwise operator needs no hand-over at
 // all -- both MFMA operands can be loaded from memory in exactly the lane layout the instruction wants:
 //
 //   * a WAVE is the unit of work, not a workgroup: item = 32 flat pixels x 128 couts (four 32x32 accumulators), walked over

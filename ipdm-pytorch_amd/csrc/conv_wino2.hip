@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     // dead from the output transform to the next tile.
     // Waves w and w + 4 share a SIMD.  Both running the same program in lockstep would stage together (the matrix pipe idle)
     // and then compete for it; waves 4-7 therefore do their staging BETWEEN the two sub-chunks, under their partners' MFMAs,
-    // and multiply while the partners stage at the chunk boundary (IPDM_WINO2_STAGGER).
+    // and multiply while the partners stage at the chunk boundary (IPDM_WINO2_STAGGER, NOTEBOOK.md).
     const bool late = (IPDM_WINO2_STAGGER == 1 && swave >= 4) || IPDM_WINO2_STAGGER == 2;
     auto chunk = [&](auto first, int ch) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first)::value;

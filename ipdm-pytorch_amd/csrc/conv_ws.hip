@@ -837,7 +837,7 @@ static int conv2d_ws_dispatch(const ConvArgs &a, hipStream_t st)
         // launches that leave most of the chip idle (one slice alone on the low-resolution levels: 64 tiles of 8x32x128 for
         // 256 channels at 125x57) run on quarter tiles (4x32 pixels x 64 couts) over the same packed weights: 4x the
         // workgroups, the same K order per output -- the choice looks at the batch and does not change a bit, like the 3x3
-        // variant above.  B = 1: 256->256 @125x57 0.059 -> see DESIGN section 6
+        // variant above.  B = 1: 256->256 @125x57 0.059 -> see NOTEBOOK.md (B = 1 latency)
         const int rows = a.w_interleave == 4 ? 8 : 16;
         const long tiles = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, rows) * cdiv(a.Cout, 32 * a.w_interleave) * a.B * (a.ksplit > 1 ? a.ksplit : 1);
         if (tiles < 128 && !opt(OPT_CONV1X1_NO_QUARTER)) {

@@ -984,7 +984,7 @@ def test_k_split_layers_on_the_winograd_kernel():
 
 
 def test_narrow_convolutions_on_the_16_cout_mfma_opt_in():
-    """conv_nm.hip (option conv_nm, off by default: DESIGN 6, negative results): the narrow stride-1 layers on
+    """conv_nm.hip (option conv_nm, off by default: NOTEBOOK.md, negative results): the narrow stride-1 layers on
     v_mfma_f32_16x16x4_f32 -- single convolutions (3x3 / 1x1, 8 and 16 couts, concat, every channel-group count, ragged
     strips, widths that are not multiples of 4, all prologues, residual) and the fused-statistics chain -- against the
     same torch references and tolerance as the default kernels."""

@@ -1,5 +1,5 @@
 // Micro-benchmark (round 4): two f32-MFMA waves per SIMD, each carrying its own share of "producer" work, against one
-// MFMA wave per SIMD with and without a specialised partner wave.  Decides the structure of conv_wino.
+// MFMA wave per SIMD with and without a specialised partner wave.  Decides the structure of conv_wino (NOTEBOOK.md).
 //
 //   per "position" a wave issues 4 dependent v_mfma_f32_32x32x2_f32 on one of 8 accumulators, then its extras:
 //     NV plain VALU (v_fma_f32), NT transcendentals (v_exp_f32), NR ds_read_b128, NW ds_write_b32, NG buffer/global b128 loads
