@@ -40,7 +40,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef IPDM_WINO2_KO
 #define IPDM_WINO2_KO 0             // compile-time timing knock-outs (tools/build_variants.sh; results are WRONG under a knock-out):
-#endif                              // 1 no activation, 2 no input transform, 4 no output transform / stores, 8 no window loads, 16 no U loads
+#endif                              // 1 no activation, 2 no input transform, 4 no output transform / stores, 8 no window loads, 16 no U loads,
+                                    // 32 output transform and exchange kept, but NO residual loads, stores or statistics (the part of the epilogue
+                                    // that could move under the next tile's first chunk: an upper bound on what deferring it can buy),
+                                    // 64 no exchange (LDS round trip + barrier E; the in-lane form of the 16x16x4 idea would remove exactly this)
 #ifndef IPDM_WINO2_STAGGER
 #define IPDM_WINO2_STAGGER 0
 #endif
@@ -491,7 +494,8 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         f32x4 rv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4, so0 + (8 * (i >> 1) + 2 * (i & 1)) * plane4, 0));
+            rv[i] = (IPDM_WINO2_KO & 32) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
+                                         : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4, so0 + (8 * (i >> 1) + 2 * (i & 1)) * plane4, 0));
         __builtin_amdgcn_sched_barrier(0);
         // columns first (in-lane): T_i[b] = sum_j M[i][j] A[j][b],  A^T = [[1,1,1,0],[0,1,-1,-1]]; then the wave's own two
         // rows (first = accumulators 0-3, second = 4-7; ih = 0: rows 0, 1, ih = 1: rows 3, 2 -- row_slot): both waves keep
@@ -508,15 +512,17 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
 #undef IPDM_M
                 K0[p] = lo0 + hi0;
                 K1[p] = lo1 + hi1;
-                *reinterpret_cast<f32x4 *>(xo + p * 256) = f32x4{hi0[0], hi0[1], hi1[0], hi1[1]};
+                if (!(IPDM_WINO2_KO & 64)) *reinterpret_cast<f32x4 *>(xo + p * 256) = f32x4{hi0[0], hi0[1], hi1[0], hi1[1]};
+                else { K0[p] += hi0 * 0.5f; K1[p] += hi1 * 0.5f; }      // (timing only: keeps the values alive without the exchange)
             }
         }
         IPDM_STAMP(5)
-        __syncthreads();                                   // E: both halves of every (tile, cout) are in LDS
+        if (!(IPDM_WINO2_KO & 64)) __syncthreads();        // E: both halves of every (tile, cout) are in LDS
         IPDM_STAMP(6)
+        f32x4 ko_sum = {0.0f, 0.0f, 0.0f, 0.0f};
         f32x4 gotv[8];                                     // partner's {T[0] c, T[0] c+1, T[1] c, T[1] c+1} of every pair
 #pragma unroll
-        for (int i = 0; i < 8; ++i) gotv[i] = *reinterpret_cast<const f32x4 *>(xr2 + i * 256);
+        for (int i = 0; i < 8; ++i) gotv[i] = (IPDM_WINO2_KO & 64) ? f32x4{K0[i][0], K0[i][1], K1[i][0], K1[i][1]} : *reinterpret_cast<const f32x4 *>(xr2 + i * 256);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int g = i >> 1, u = 2 * (i & 1);
@@ -535,6 +541,11 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
             f32x4 v = {ya0, ya1, yb0, yb1};
             const int so = so0 + (8 * g + u) * plane4;
             v += rv[i];
+            if (IPDM_WINO2_KO & 32) {      // (timing only: ONE store per tile, of the sum of all eight results, keeps the transform alive)
+                ko_sum += v;
+                if (i == 7) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ko_sum), o_rsrc, voff4, so, 0);
+                continue;
+            }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4, so, 0);
             if (ragged) {            // (wave-uniform) the run that straddles the edge: element by element, by its lane
 #pragma unroll

@@ -1755,9 +1755,12 @@ ARBITER_MEDIAN_RMS, ARBITER_MEDIAN_MAX = 1.25, 1.5       # median over the seeds
 # ratios 0.99 ... 1.03, max-abs 0.93 ... 1.24 (nothing amplifies there: both evaluations end 1.3e-7 rms from the arbiter).  The
 # reduced random-weight networks amplify rounding chaotically: over five weight seeds the float32 ORACLE's own distance to the
 # arbiter spans 1.9e-7 ... 4.3e-4 rms, and the ratio of two such samples 0.86 ... 2.16 (rms), 0.75 ... 2.48 (max-abs) around
-# a median of 1.00 / 1.32 -- a single seed's ratio is noise, the median is the measurement.  Round 5: caps 4 -> 3 (the measured
-# worst is 2.48), seven seeds in the reduced statistic, the stage-by-stage test judged by its median behind the amplifying pass.
-ARBITER_WORST_RMS, ARBITER_WORST_MAX = 3.0, 3.0
+# a median of 1.00 / 1.32 -- a single seed's ratio is noise, the median is the measurement.  Round 5: seven seeds in the reduced
+# statistic (median 0.89 / 1.13, profiles/r05_arbiter_reduced_pipeline.txt), the stage-by-stage test judged by its median behind
+# the amplifying pass, caps 4 -> 3 in rms and 3.5 in max-abs: the worst seed (the fourth) read 2.16 / 2.48 in round 4 and
+# 2.17 / 2.67 in round 5 with nothing changed on the device side -- the CPU oracle's own float32 replay moves with its host's
+# thread schedule, and the max over pixels of two chaotic evaluations is the noisier of the two statistics.
+ARBITER_WORST_RMS, ARBITER_WORST_MAX = 3.0, 3.5
 
 
 def _arbiter_ratios(tag, hips, c32s, f64s):
