@@ -114,7 +114,9 @@ __device__ inline float sum_row16(float x)              // over the 16 lanes of 
 }
 #undef IPDM_DPP_F
 
-template <bool PLANAR>
+// RES: the layer adds a residual; layers without one run an instantiation that issues no residual loads (round 5: a
+// vector-memory instruction costs its issue slot whatever it fetches, conv_wino2.hip has the measurement)
+template <bool PLANAR, bool RES>
 __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -603,7 +605,8 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
         f32x4 rv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4, so0 + (8 * (i >> 1) + 2 * (i & 1)) * plane4, 0));
+            rv[i] = RES ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4, so0 + (8 * (i >> 1) + 2 * (i & 1)) * plane4, 0))
+                        : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         __builtin_amdgcn_sched_barrier(0);
         // columns first (in-lane): T_i[b] = sum_j M[i][j] A[j][b],  A^T = [[1,1,1,0],[0,1,-1,-1]]; then the wave's own two
         // rows (first = accumulators 0-3, second = 4-7; ih = 0: rows 0, 1, ih = 1: rows 3, 2 -- row_slot): both waves keep
@@ -655,7 +658,7 @@ __global__ void __launch_bounds__(512) conv_wino_kernel(ConvArgs a, int ntiles)
                 for (int e = 0; e < 4; ++e) {
                     const int vo1 = (part && e < nval) ? lane_off4 + 4 * e : OOB;
                     float x = v[e];
-                    if (a.res) x += bload(r_rsrc, vo1, so);        // (the lane's 16-byte residual load was out of range: + 0 above)
+                    if (RES) x += bload(r_rsrc, vo1, so);          // (the lane's 16-byte residual load was out of range: + 0 above)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), o_rsrc, vo1, so, 0);
                     if (part) v[e] = e < nval ? x : 0.0f;
                 }
@@ -774,15 +777,19 @@ int conv2d_wino_launch(const ConvArgs &args, hipStream_t st)
     const int cus = device_cu_count();
     int G = (int)(ntiles < cus ? ntiles : cus);
     G = (G + 7) / 8 * 8;
-    const void *fn = a.x1_planar ? (const void *)conv_wino_kernel<true> : (const void *)conv_wino_kernel<false>;
+    const bool res = a.res != nullptr;
+    const void *fn = a.x1_planar ? (res ? (const void *)conv_wino_kernel<true, true> : (const void *)conv_wino_kernel<true, false>)
+                                 : (res ? (const void *)conv_wino_kernel<false, true> : (const void *)conv_wino_kernel<false, false>);
     if (int rc = ensure_dynamic_lds(fn, LDS_BYTES)) return rc;
     const bool prof = prof_enabled(), v2 = a.ksplit > 1 || (!opt(OPT_WINO_V1) && conv_wino2_eligible(a));
     IPDM_REQUIRE(a.ksplit == 1 || conv_wino2_eligible(a), "conv2d_wino: this layer cannot be split into %d K slices", a.ksplit);
     if (prof) prof_before(v2 ? 5 : 3, st);
     if (v2) {
         if (int rc = conv2d_wino2_launch(a, st)) return rc;
-    } else if (a.x1_planar) hipLaunchKernelGGL(conv_wino_kernel<true>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
-    else hipLaunchKernelGGL(conv_wino_kernel<false>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    } else if (a.x1_planar && res) hipLaunchKernelGGL((conv_wino_kernel<true, true>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    else if (a.x1_planar) hipLaunchKernelGGL((conv_wino_kernel<true, false>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    else if (res) hipLaunchKernelGGL((conv_wino_kernel<false, true>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    else hipLaunchKernelGGL((conv_wino_kernel<false, false>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
     // EXECUTED flops: 16 multiply-adds per 2x2 output tile and (cin, cout) pair (the 3x3 form counts 36)
     if (prof) prof_after(v2 ? 5 : 3, 2.0 * a.B * (double)cdiv(a.Ho, 2) * cdiv(a.Wo, 2) * 16.0 * a.Cout * (a.C1 + a.C2), st);
     IPDM_LAUNCH_CHECK();

@@ -47,6 +47,15 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef IPDM_WINO2_STAGGER
 #define IPDM_WINO2_STAGGER 0
 #endif
+#ifndef IPDM_WINO2_SGN
+#define IPDM_WINO2_SGN 1            // 1: the GroupNorm scale / shift of the wave's two channels through SCALAR loads (two s_load_dwordx2 per chunk
+#endif                              //    instead of four per-lane dword buffer loads: 4 of the 22 vector-memory instructions of a chunk) -- round 5 experiment
+#ifndef IPDM_WINO2_NTSTORE
+#define IPDM_WINO2_NTSTORE 0        // 1: the output runs with non-temporal stores -- round 5 experiment
+#endif
+#ifndef IPDM_WINO2_DEFER
+#define IPDM_WINO2_DEFER 0          // 1: the eight 16-byte stores of an interior tile are issued under the NEXT tile's first MFMAs (round 5 experiment)
+#endif
 #ifndef IPDM_CONV_STAMPS
 #define IPDM_CONV_STAMPS 0          // `make stamps`: in-kernel s_memtime stamps of the phases (a stamped build changes what it measures)
 #endif
@@ -94,7 +103,11 @@ __device__ inline float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff)
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-template <bool PLANAR>
+#ifndef IPDM_WINO2_RES_T
+#define IPDM_WINO2_RES_T 1          // 1: layers WITHOUT a residual run an instantiation that issues no residual loads (0: the round-4 form, eight
+#endif                              //    range-checked-away loads per tile and wave: a vector-memory instruction costs its issue slot whatever it fetches)
+// RES: the layer adds a residual (conv2 of a ResidualBlock with an identity or launched shortcut)
+template <bool PLANAR, bool RES>
 __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -218,7 +231,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         for (int j = 0; j < 2; ++j) va[j] = (PLANAR && starts_in_x1) ? vop[PLANAR ? j : 0] : vo[j];
         g_sa = (PLANAR && starts_in_x1) ? g_sop : g_so;
     };
-    struct Raw { f32x4 v[2]; float sc[2], sh[2]; bool planar; };
+    struct Raw { f32x4 v[2]; float sc[2], sh[2]; bool planar; float ssc[2], ssh[2]; };      // (ssc / ssh: wave-uniform, IPDM_WINO2_SGN)
     Raw raw;
     const __amdgpu_buffer_rsrc_t gsc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.act ? a.gn_scale : a.out), 0, a.act ? (a.B * Ctot + 64) * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t gsh_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.act ? a.gn_shift : a.out), 0, a.act ? (a.B * Ctot + 64) * 4 : 0, 0x00020000);
@@ -242,8 +255,16 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {                        // (the slot's channel: a per-lane offset; the planar slot map differs)
             const int go = (PLANAR && raw.planar) ? gnoffp[PLANAR ? j : 0] : gnoff[j];
-            raw.sc[j] = bload(gsc_rsrc, go, gso);
-            raw.sh[j] = bload(gsh_rsrc, go, gso);
+            if (!IPDM_WINO2_SGN) {
+                raw.sc[j] = bload(gsc_rsrc, go, gso);
+                raw.sh[j] = bload(gsh_rsrc, go, gso);
+            }
+        }
+        if (IPDM_WINO2_SGN && a.act) {          // (uniform address: s_load_dwordx2; the arrays carry a chunk of read-ahead past [B, Ctot])
+            const int gi = __builtin_amdgcn_readfirstlane(g_n * Ctot + c0 + 2 * swave);
+            const float *__restrict__ ps = a.gn_scale + gi, *__restrict__ ph = a.gn_shift + gi;
+            raw.ssc[0] = ps[0]; raw.ssc[1] = ps[1];
+            raw.ssh[0] = ph[0]; raw.ssh[1] = ph[1];
         }
     };
     // activate the 8 landed values, zero what lies outside the image, park them in the wave's scratch
@@ -260,6 +281,11 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         if (a.act) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if (IPDM_WINO2_SGN && !(e & 1)) {      // (the slot's channel: the first or the second of the wave's two)
+                    const bool second = ((PLANAR && raw.planar) ? gnoffp[PLANAR ? (e >> 1) : 0] : gnoff[e >> 1]) != 0;
+                    raw.sc[e >> 1] = second ? raw.ssc[1] : raw.ssc[0];
+                    raw.sh[e >> 1] = second ? raw.ssh[1] : raw.ssh[0];
+                }
                 const f32x2 sc2 = {raw.sc[e >> 1], raw.sc[e >> 1]}, sh2 = {raw.sh[e >> 1], raw.sh[e >> 1]};
                 d[e] = __builtin_elementwise_fma(d[e], sc2, sh2);
             }
@@ -388,6 +414,20 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
 
     int s = 0;                                             // running chunk index (V stage parity)
     int k = 0;
+    // deferred stores (IPDM_WINO2_DEFER): the finished 4-pixel runs of the previous tile, stored two per position under the first
+    // sixteen MFMAs of this tile -- their registers are the ones the accumulators started last will take
+    // (the stores are issued UNCONDITIONALLY, with an out-of-range offset when there is nothing to store: a conditionally issued
+    //  memory operation makes the wait-count pass assume the shorter path, and every wait behind it comes out too strict)
+    int d_voff = OOB;
+    f32x4 d_v[8];
+    size_t d_sample = 0;
+    int d_so0 = 0;
+    const int d_lane_off4 = ((lk * 4 + odd) * out_plane + (2 * ty + ih) * a.Wo + 4 * txh) * 4;
+    typedef unsigned du32x4 __attribute__((ext_vector_type(4)));
+    auto deferred_store = [&](int i) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + d_sample), 0, a.Cout * out_plane * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(du32x4, d_v[i]), rs, d_voff, d_so0 + (8 * (i >> 1) + 2 * (i & 1)) * plane4, 0);
+    };
     const bool stamp = IPDM_CONV_STAMPS && (a.dbg & 8) != 0;
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;      // stage / multiply / transform / barrier / epilogue
     const unsigned long long st_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
@@ -446,6 +486,11 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
                 for (int qq = 1; qq < 4; ++qq) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e][qq], b_c[qq], acc[e], 0, 0, 0);
                 // the U of this position for the NEXT sub-chunk, into the registers just read
                 if (!(IPDM_WINO2_KO & 16)) issue_u(e, kc == 0 ? 2 * ch + 1 : 2 * ch1);
+                if (IPDM_WINO2_DEFER && FIRST && kc == 0 && e < 4) {
+                    deferred_store(2 * e);
+                    deferred_store(2 * e + 1);
+                    if (e == 3) d_voff = OOB;
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (e + 1 < 8) b_c = b_n;
             }
@@ -494,7 +539,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         f32x4 rv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            rv[i] = (IPDM_WINO2_KO & 32) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
+            rv[i] = ((IPDM_WINO2_KO & 32) || !RES) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
                                          : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff4, so0 + (8 * (i >> 1) + 2 * (i & 1)) * plane4, 0));
         __builtin_amdgcn_sched_barrier(0);
         // columns first (in-lane): T_i[b] = sum_j M[i][j] A[j][b],  A^T = [[1,1,1,0],[0,1,-1,-1]]; then the wave's own two
@@ -546,13 +591,16 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
                 if (i == 7) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ko_sum), o_rsrc, voff4, so, 0);
                 continue;
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4, so, 0);
+            // (IPDM_WINO2_DEFER: an interior tile -- wave-uniform: every lane owns its whole run -- keeps its runs for the next tile's
+            //  first MFMAs; d_v is DEFINED on every path so that its live range ends at the deferred stores)
+            if (IPDM_WINO2_DEFER) d_v[i] = v;
+            if (!(IPDM_WINO2_DEFER && !clipped && !ragged)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4, so, IPDM_WINO2_NTSTORE ? 2 : 0);
             if (ragged) {            // (wave-uniform) the run that straddles the edge: element by element, by its lane
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int vo1 = (part && e < nval) ? lane_off4 + 4 * e : OOB;
                     float x = v[e];
-                    if (a.res) x += bload(r_rsrc, vo1, so);        // (the lane's 16-byte residual load was out of range: + 0 above)
+                    if (RES) x += bload(r_rsrc, vo1, so);          // (the lane's 16-byte residual load was out of range: + 0 above)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), o_rsrc, vo1, so, 0);
                     if (part) v[e] = e < nval ? x : 0.0f;
                 }
@@ -589,8 +637,13 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if (IPDM_WINO2_DEFER && !clipped && !ragged) { d_voff = d_lane_off4; d_sample = sample; d_so0 = so0; }
         asm volatile("s_nop 7");      // (store data registers vs the first VALU write of the next tile, across the back edge: conv_pw.hip)
         IPDM_STAMP(4)
+    }
+    if (IPDM_WINO2_DEFER) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) deferred_store(i);
     }
     if (stamp && tid == 0) {
         unsigned long long *d = a.dbg_buf + (size_t)blockIdx.x * 8;
@@ -647,10 +700,14 @@ int conv2d_wino2_launch(const ConvArgs &prepared, hipStream_t st)
     const int cus = device_cu_count();
     long G = ntiles < cus ? ntiles : cus;
     G = (G + 7) / 8 * 8;
-    const void *fn = a.x1_planar ? (const void *)conv_wino2_kernel<true> : (const void *)conv_wino2_kernel<false>;
+    const bool res = a.res != nullptr || !IPDM_WINO2_RES_T;
+    const void *fn = a.x1_planar ? (res ? (const void *)conv_wino2_kernel<true, true> : (const void *)conv_wino2_kernel<true, false>)
+                                 : (res ? (const void *)conv_wino2_kernel<false, true> : (const void *)conv_wino2_kernel<false, false>);
     if (int rc = ensure_dynamic_lds(fn, LDS_BYTES)) return rc;
-    if (a.x1_planar) hipLaunchKernelGGL(conv_wino2_kernel<true>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
-    else hipLaunchKernelGGL(conv_wino2_kernel<false>, dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    if (a.x1_planar && res) hipLaunchKernelGGL((conv_wino2_kernel<true, true>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    else if (a.x1_planar) hipLaunchKernelGGL((conv_wino2_kernel<true, false>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    else if (res) hipLaunchKernelGGL((conv_wino2_kernel<false, true>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
+    else hipLaunchKernelGGL((conv_wino2_kernel<false, false>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
     return IPDM_OK;
 }
 
