@@ -638,7 +638,10 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
             __builtin_amdgcn_wave_barrier();
         }
         if (IPDM_WINO2_DEFER && !clipped && !ragged) { d_voff = d_lane_off4; d_sample = sample; d_so0 = so0; }
-        asm volatile("s_nop 7");      // (store data registers vs the first VALU write of the next tile, across the back edge: conv_pw.hip)
+        // (wait states between the tile's last 16-byte stores and whatever writes their data registers next: gfx950 needs ONE for a
+        //  buffer store with an SGPR soffset too, the compiler inserts none -- NOTEBOOK.md round 5; tools/check_store_hazard.py scans
+        //  every kernel of the library for the pair at build time)
+        asm volatile("s_nop 7");
         IPDM_STAMP(4)
     }
     if (IPDM_WINO2_DEFER) {

@@ -217,6 +217,9 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
         // + bias: one MFMA per accumulator (pixel operand 1 on k step 0, weight operand = the bias there)
 #pragma unroll
         for (int r = 0; r < RPW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(lk ? 0.0f : 1.0f, nb, acc[r], 0, 0, 0);
+#ifdef PW_NOP_AFTER_BIAS                // (pw_repro.hip bisect: 64 wait states between the bias MFMAs and the first read of their results)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
         const Item t = cur;
         cur = Item{g_n, g_p0, g_co};                         // (describe(k + 1) ran two chunks ago)
         if (k + 1 < n_my) fetch_bias(cur.co0);
@@ -246,6 +249,9 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v = {acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]};
+#ifdef PW_OPAQUE_COPY                   // (pw_repro.hip bisect: the stored values pass through an opaque VALU-visible copy)
+                asm volatile("" : "+v"(v));
+#endif
                 const int pq = pw0 + 32 * r + 8 * q;
                 const int so = so0 + (32 * r + 8 * q) * 4;
                 if (a.res) {
@@ -254,6 +260,12 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
                 }
                 if (!tail) {
                     if (!(IPDM_PW_KO & 4) || pq == 12345) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, lane_off, so, 0);
+#ifdef PW_DRAIN_AFTER_STORE             // (pw_repro.hip bisect: every store has completed before anything else happens)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifdef PW_NOP_AFTER_STORE               // (pw_repro.hip bisect: PW_NOP_AFTER_STORE + 1 wait states between a 16-byte store and whatever writes its
+                    asm volatile("s_nop %0" :: "n"(PW_NOP_AFTER_STORE) : "memory");      //  data registers next: -DPW_NOP_AFTER_STORE=0 is ONE wait state)
+#endif
                 } else {                                     // (uniform) the last tile of a plane: whole runs, then the partial one by element
                     const int nval = HW - pq;                // valid pixels of the lane's run (>= 4: whole)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, nval >= 4 ? lane_off : OOB, so, 0);
@@ -286,7 +298,9 @@ __global__ void __launch_bounds__(512) conv_pw_kernel(ConvArgs a, int nitems)
         // registers at the head of the next chunk is across the loop's back edge, where the compiler's hazard recogniser does
         // not look: without these wait states the store read zeros (the next stage offset) for lanes 12-15 of every row of
         // 16 (found by tools/pw_check.py: a few wrong pixels, run-dependent).
+#ifndef PW_NO_TAIL_WAIT                 // (pw_repro.hip: -DPW_NO_TAIL_WAIT builds the kernel WITHOUT these wait states)
         asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7" ::: "memory");
+#endif
         ++k;
     }
 }
