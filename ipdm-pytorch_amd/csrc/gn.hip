@@ -172,6 +172,19 @@ __global__ void __launch_bounds__(256) gn_group_kernel(GnTileArgs a)
         const int cl = c < C0 ? c : c - C0;
         const float2 *p = reinterpret_cast<const float2 *>(src.stats) + (size_t)n * src.rows * src.C + cl;
         int r = ro;
+        // sixteen independent loads in flight (round 5): a block walks its rows alone -- 64 per thread on the 512x512 level --
+        // and the walk is a chain of memory latencies, 7 us per launch for a lone slice and 70 launches per forward.  The sums
+        // are formed in groups of four exactly as the four-wide loop below forms them: the same bits.
+        for (; r + 15 * rpi < src.rows; r += 16 * rpi) {
+            float2 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(r + j * rpi) * src.C];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                sum += (double)v[j].x + (double)v[j + 1].x + (double)v[j + 2].x + (double)v[j + 3].x;
+                sq += (double)v[j].y + (double)v[j + 1].y + (double)v[j + 2].y + (double)v[j + 3].y;
+            }
+        }
         for (; r + 3 * rpi < src.rows; r += 4 * rpi) {            // four independent loads in flight
             const float2 v0 = p[(size_t)r * src.C], v1 = p[(size_t)(r + rpi) * src.C],
                          v2 = p[(size_t)(r + 2 * rpi) * src.C], v3 = p[(size_t)(r + 3 * rpi) * src.C];
