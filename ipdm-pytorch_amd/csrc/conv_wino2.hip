@@ -53,6 +53,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef IPDM_WINO2_NTSTORE
 #define IPDM_WINO2_NTSTORE 0        // 1: the output runs with non-temporal stores -- round 5 experiment
 #endif
+#ifndef IPDM_WINO2_PKT
+#define IPDM_WINO2_PKT 1            // 1: the input transform of the NCHW instantiations as sixteen packed-f32 adds (0: the scalar form; same bits)
+#endif
 #ifndef IPDM_WINO2_DEFER
 #define IPDM_WINO2_DEFER 0          // 1: the eight 16-byte stores of an interior tile are issued under the NEXT tile's first MFMAs (round 5 experiment)
 #endif
@@ -352,6 +355,7 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
     const int v_slot = (w_tx & 1) * 16 + (w_tx >> 1) * 2 + w_ty;                    // MFMA lane of tile (row w_ty, column w_tx)
     const int v_lane = (swave >> 2) * VH_FLOATS + (lk * 32 + v_slot) * 4 + (swave & 3);      // + xi * 256 (+ stage)
     float patch[16];
+    f32x2 pp[4][2];                                                                  // the same patch as aligned column pairs (IPDM_WINO2_PKT)
     constexpr int pcol[4] = {0, PLANAR ? 2 : 1, PLANAR ? 1 : 2, 3};                  // register position of patch column c
     auto read_patch = [&]() __attribute__((always_inline)) {
         const float *const xrp = xr - w_tx;                                         // column pairs (tx, tx + 1) of both halves
@@ -365,12 +369,43 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const f32x2 lo = *reinterpret_cast<const f32x2 *>(xr + r * XP), hi = *reinterpret_cast<const f32x2 *>(xr + r * XP + 2);
-                patch[4 * r] = lo[0]; patch[4 * r + 1] = lo[1]; patch[4 * r + 2] = hi[0]; patch[4 * r + 3] = hi[1];
+                if (IPDM_WINO2_PKT) { pp[r][0] = lo; pp[r][1] = hi; }
+                else { patch[4 * r] = lo[0]; patch[4 * r + 1] = lo[1]; patch[4 * r + 2] = hi[0]; patch[4 * r + 3] = hi[1]; }
             }
         }
     };
     // B^T d B of the lane's 4x4 patch into V stage `par`
     auto transform_patch = [&](int par) __attribute__((always_inline)) {
+        if (IPDM_WINO2_PKT && !PLANAR) {
+            // The same sixteen differences and sums as below, as SIXTEEN packed-f32 instructions instead of ~30 (round 5: the
+            // kernel's non-MFMA vector instructions take 0.14 of the SIMD's time, profiles/r05_pmc_wino2alu_*): rows first on the
+            // aligned column pairs {c0, c1}, {c2, c3} (plain packed adds), then per row the pairs (o0, o1) = (t0 - t2, t1 + t2) and
+            // (o2, o3) = (t2 - t1, t1 - t3) through the half selects and per-lane negations of v_pk_add_f32.  Every result is one
+            // IEEE add / subtract of the same two values as in the scalar form: the same bits.
+            f32x2 T[4][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {      // (inline asm: left to itself the compiler takes half of these apart into scalar adds)
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(T[0][h]) : "v"(pp[0][h]), "v"(pp[2][h]));
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(T[1][h]) : "v"(pp[1][h]), "v"(pp[2][h]));
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(T[2][h]) : "v"(pp[2][h]), "v"(pp[1][h]));
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(T[3][h]) : "v"(pp[1][h]), "v"(pp[3][h]));
+            }
+            float *vd = lds + par * V_FLOATS + v_lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rs = row_slot(i);
+                f32x2 o01, o23;
+                // low lane: t0 + (-t2)          high lane: t1 + t2
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(o01) : "v"(T[i][0]), "v"(T[i][1]));
+                // low lane: t2 + (-t1)          high lane: (-t3) + t1
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(o23) : "v"(T[i][1]), "v"(T[i][0]));
+                vd[(rs * 4 + 0) * 256] = o01[0];
+                vd[(rs * 4 + 1) * 256] = o01[1];
+                vd[(rs * 4 + 2) * 256] = o23[0];
+                vd[(rs * 4 + 3) * 256] = o23[1];
+            }
+            return;
+        }
         float tt[16];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
