@@ -42,6 +42,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // excepted), so a switch flipped between create and forward is an error, not a silently mismatched layout.
 enum Opt {
     OPT_CONV_NO_UP2,         // Upsample layers in the reference's 3x3 form (per call: both weight sets are packed)
+    OPT_CONV_NO_WUP2,        // wide Upsample layers on the 2x2-tap parity kernel instead of its F(2x2,2x2) form (per call; conv_wup2.hip)
     OPT_CONV_LEGACY, OPT_CONV1X1_LEGACY, OPT_CONVS2_LEGACY,      // route kernel families to the round-1 4-wave kernels
     OPT_CONV_NO_DIRECT, OPT_DIRECT_NO_PLANAR, OPT_DIRECT_MAX_CIN, OPT_DIRECT_NO_S2, OPT_DIRECT_NO_SKIP_FUSE,
     OPT_CONV_DBG, OPT_CONV_VEC4_STRICT, OPT_CONV_NO_SPLITK, OPT_CONV_NO_WINO, OPT_WINO_V1, OPT_WINO2_MIN_TILES, OPT_CONV1X1_NO_QUARTER, OPT_CONV_NO_PW, OPT_PW_ITEM, OPT_PW_FORCE,

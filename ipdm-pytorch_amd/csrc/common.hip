@@ -27,6 +27,7 @@ namespace {
 struct OptDef { const char *name; int def; bool per_call; int lo = 0, hi = 1; };      // [lo, hi]: what ipdm_set_option accepts
 const OptDef g_opt_def[OPT_COUNT] = {
     {"conv_no_up2", 0, true},
+    {"conv_no_wup2", 0, true},
     {"conv_legacy", 0, false}, {"conv1x1_legacy", 0, false}, {"convs2_legacy", 0, false},
     {"conv_no_direct", 0, false}, {"direct_no_planar", 0, false},
     {"direct_max_cin", 160, false, 0, 160},      // (conv_direct's LDS staging and chunk loop are sized for at most 160 input channels)

@@ -387,7 +387,7 @@ int conv_kernel_code(const ConvArgs &a)
 {
     if (a.w_interleave) {
         if (conv_pw_eligible(a)) return 10;
-        if (conv_up2_eligible(a)) return 7;
+        if (conv_up2_eligible(a)) return conv_wup2_eligible(a) ? 11 : 7;
         if (conv_wino_eligible(a)) {
             if (a.split_ws && conv_split(a) > 1) return 9;
             return (!opt(OPT_WINO_V1) && conv_wino2_eligible(a)) ? 2 : 1;

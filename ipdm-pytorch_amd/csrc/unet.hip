@@ -311,6 +311,7 @@ namespace {
 // w_up2 / w_up2_t: the Upsample convolutions' parity form (conv_pack_weights_up2), null elsewhere
 struct ConvP { float *w = nullptr; float *w_t = nullptr; float *b = nullptr; int cin = 0, cout = 0, ks = 0, cout_pad = 0, interleave = 0;
                float *w_up2 = nullptr, *w_up2_t = nullptr;
+               float *w_wup2 = nullptr, *w_wup2_t = nullptr;      // ... in the F(2x2,2x2) domain (conv_pack_weights_wup2), wide layers
                float *w_wino = nullptr, *w_wino_t = nullptr; };      // Winograd-domain weights (conv_pack_weights_wino), both orientations
 struct NormP { float *g = nullptr, *b = nullptr; int ch = 0, groups = 0; };
 struct ResP { NormP n1, n2; ConvP c1, c2, sc; bool has_sc = false; int bias_off = 0;      // bias_off into bias_eff
@@ -456,6 +457,12 @@ int make_conv(ipdm_unet *net, const WeightMap &wm, const std::string &wname, con
             if ((rc = upload(net, packed.data(), packed.size(), &out.w_up2))) return rc;
             conv_pack_weights_up2(wt.data(), cout, cin, out.interleave, packed);
             if ((rc = upload(net, packed.data(), packed.size(), &out.w_up2_t))) return rc;
+            if (out.interleave && conv_wup2_shape_ok(cout, cin)) {
+                conv_pack_weights_wup2(w, cout, cin, packed);
+                if ((rc = upload(net, packed.data(), packed.size(), &out.w_wup2))) return rc;
+                conv_pack_weights_wup2(wt.data(), cout, cin, packed);
+                if ((rc = upload(net, packed.data(), packed.size(), &out.w_wup2_t))) return rc;
+            }
         }
     }
     out.b = nullptr;
@@ -676,6 +683,7 @@ struct Fwd {
         a.w_interleave = cp.interleave; a.cout_pad = cp.cout_pad;
         a.Hs = x1->H; a.Ws = x1->W; a.H = H; a.W = W; a.upsample = (H != x1->H || W != x1->W); a.act = act; a.res = res ? (const float *)(uintptr_t)256 : nullptr;
         a.w_up2 = net->transposed ? cp.w_up2_t : cp.w_up2;
+        a.w_wup2 = net->transposed ? cp.w_wup2_t : cp.w_wup2;
         a.w_wino = net->transposed ? cp.w_wino_t : cp.w_wino;
         // parity-planar sources (outputs of up2 convolutions): x1 of the kernels that can read them, converted otherwise
         Tensor *lin1 = nullptr, *lin2 = linear_copy(x2), *linr = linear_copy(res);
@@ -1138,11 +1146,12 @@ extern "C" int ipdm_op_up_conv_chain(const float *d_x, int32_t C, int32_t B, int
                  "op_up_conv_chain: null argument");
     hipStream_t st = (hipStream_t)stream;
     const int H = 2 * Hs, W = 2 * Ws, Cc = CA + C2;
-    std::vector<float> pA, pU, pB;
+    std::vector<float> pA, pU, pB, pW;
     int cinp, coutpA, coutpB;
     const int ilA = conv_weight_interleave(CA, 3, 1), ilB = conv_weight_interleave(CB, ksB, 1);
     conv_pack_weights(wA_host, CA, C, 3, ilA, pA, cinp, coutpA);
     if (ilA == 2 || ilA == 4 || (ilA == 0 && CA <= 16)) conv_pack_weights_up2(wA_host, CA, C, ilA, pU);
+    if (ilA && conv_wup2_shape_ok(CA, C)) conv_pack_weights_wup2(wA_host, CA, C, pW);
     conv_pack_weights(wB_host, CB, Cc, ksB, ilB, pB, cinp, coutpB);
     std::vector<void *> tofree;
     auto dev = [&](const void *h, size_t bytes, void **out) -> int {
@@ -1154,10 +1163,12 @@ extern "C" int ipdm_op_up_conv_chain(const float *d_x, int32_t C, int32_t B, int
         *out = d;
         return IPDM_OK;
     };
+    float *d_wW = nullptr;
     float *d_wA, *d_wU = nullptr, *d_wB, *d_bA = nullptr, *d_bB = nullptr, *d_g, *d_be, *d_sc, *d_sh, *d_stats = nullptr, *d_pl = nullptr, *d_lin = nullptr;
     double *d_part;
     int rc = dev(pA.data(), pA.size() * 4, (void **)&d_wA);
     if (!rc && !pU.empty()) rc = dev(pU.data(), pU.size() * 4, (void **)&d_wU);
+    if (!rc && !pW.empty()) rc = dev(pW.data(), pW.size() * 4, (void **)&d_wW);
     if (!rc) rc = dev(pB.data(), pB.size() * 4, (void **)&d_wB);
     if (!rc && bA_host) rc = dev(bA_host, CA * 4, (void **)&d_bA);
     if (!rc && bB_host) rc = dev(bB_host, CB * 4, (void **)&d_bB);
@@ -1169,11 +1180,12 @@ extern "C" int ipdm_op_up_conv_chain(const float *d_x, int32_t C, int32_t B, int
     if (!rc) rc = dev(nullptr, (size_t)B * CA * H * W * 4, (void **)&d_pl);
     ConvArgs a;
     a.x1 = d_x; a.x2 = nullptr; a.C1 = C; a.C2 = 0; a.B = B; a.Hs = Hs; a.Ws = Ws; a.H = H; a.W = W; a.upsample = 1;
-    a.scale_y = (float)Hs / (float)H; a.scale_x = (float)Ws / (float)W; a.w = d_wA; a.w_up2 = d_wU; a.cout_pad = coutpA; a.w_interleave = ilA;
+    a.scale_y = (float)Hs / (float)H; a.scale_x = (float)Ws / (float)W; a.w = d_wA; a.w_up2 = d_wU; a.w_wup2 = d_wW; a.cout_pad = coutpA; a.w_interleave = ilA;
     a.bias = d_bA; a.Cout = CA; a.ksize = 3; a.stride = 1; a.Ho = H; a.Wo = W; a.act = 0; a.gn_scale = a.gn_shift = nullptr; a.res = nullptr;
     a.out = d_pl; a.tiles_x = a.tiles_y = a.co_tiles = 0;
     const bool up2 = conv_up2_eligible(a);
-    if (used_up2) *used_up2 = up2 ? 1 : (conv_direct_up2_eligible(a) ? 2 : 0);      // 2: the direct kernel's parity form (NCHW output)
+    // 2: the direct kernel's parity form (NCHW output); 3: the F(2x2,2x2) form of the wide layers (conv_wup2.hip)
+    if (used_up2) *used_up2 = up2 ? (conv_wup2_eligible(a) ? 3 : 1) : (conv_direct_up2_eligible(a) ? 2 : 0);
     const int rows = C2 == 0 ? conv_stats_rows(a) : 0;      // fused statistics when the GroupNorm covers mid alone
     if (!rc && rows > 0) {
         rc = dev(nullptr, (size_t)B * rows * CA * 2 * 4, (void **)&d_stats);
@@ -1305,9 +1317,12 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
 {
     IPDM_REQUIRE(avg_ms && iters > 0, "bench_conv2d: bad argument");
     const bool x1_planar = (act & 256) != 0;          // tuning aid: time the kernel's parity-planar reader path (x1 as an up2 output)
+    const bool up = (act & 512) != 0;                 // tuning aid: an Upsample layer (nearest 2x + 3x3) whose SOURCE is H x W
     act &= 255;
+    IPDM_REQUIRE(!up || (ksize == 3 && stride == 1 && !C2 && !with_res && !act && !x1_planar), "bench_conv2d: bad Upsample configuration");
     const int Cin = C1 + C2, pad = ksize / 2;
-    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const int Hv = up ? 2 * H : H, Wv = up ? 2 * W : W;
+    const int Ho = (Hv + 2 * pad - ksize) / stride + 1, Wo = (Wv + 2 * pad - ksize) / stride + 1;
     std::vector<float> w((size_t)Cout * Cin * ksize * ksize), packed;
     for (size_t i = 0; i < w.size(); ++i) w[i] = (float)((i * 2654435761u) % 2001) / 1000.0f - 1.0f;
     int cin_pad, cout_pad;
@@ -1330,9 +1345,24 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     ipdm_randn(d_sc, 1, (int64_t)B * Cin, 4, 0, 0, nullptr);
     ipdm_randn(d_sh, 1, (int64_t)B * Cin, 5, 0, 0, nullptr);
     ipdm_randn(d_b, 1, Cout, 6, 0, 0, nullptr);
+    float *d_wU = nullptr, *d_wW = nullptr;
+    if (up) {
+        std::vector<float> pk;
+        if (interleave == 2 || interleave == 4) {
+            conv_pack_weights_up2(w.data(), Cout, Cin, interleave, pk);
+            IPDM_HIP_CHECK(hipMalloc((void **)&d_wU, pk.size() * 4));
+            IPDM_HIP_CHECK(hipMemcpy(d_wU, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+            if (conv_wup2_shape_ok(Cout, Cin)) {
+                conv_pack_weights_wup2(w.data(), Cout, Cin, pk);
+                IPDM_HIP_CHECK(hipMalloc((void **)&d_wW, pk.size() * 4));
+                IPDM_HIP_CHECK(hipMemcpy(d_wW, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+            }
+        }
+    }
     ConvArgs a;
-    a.x1 = d_x1; a.x2 = d_x2; a.C1 = C1; a.C2 = C2; a.B = B; a.Hs = H; a.Ws = W; a.H = H; a.W = W; a.upsample = 0;
-    a.scale_y = a.scale_x = 1.f; a.w = d_w; a.w_wino = d_wino; a.cout_pad = cout_pad; a.w_interleave = interleave; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
+    a.x1 = d_x1; a.x2 = d_x2; a.C1 = C1; a.C2 = C2; a.B = B; a.Hs = H; a.Ws = W; a.H = Hv; a.W = Wv; a.upsample = up ? 1 : 0;
+    a.w_up2 = d_wU; a.w_wup2 = d_wW;
+    a.scale_y = a.scale_x = up ? 0.5f : 1.f; a.w = d_w; a.w_wino = d_wino; a.cout_pad = cout_pad; a.w_interleave = interleave; a.bias = d_b; a.Cout = Cout; a.ksize = ksize; a.stride = stride;
     a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
     a.tiles_x = a.tiles_y = a.co_tiles = 0;
     if (x1_planar) { IPDM_REQUIRE(conv_planar_ok(a), "bench_conv2d: this shape has no parity-planar reader"); a.x1_planar = 1; }
@@ -1365,6 +1395,7 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     }
     (void)hipFree(d_split);
     (void)hipFree(d_wino);
+    (void)hipFree(d_wU); (void)hipFree(d_wW);
     (void)hipFree(d_w); (void)hipFree(d_x1); (void)hipFree(d_x2); (void)hipFree(d_out); (void)hipFree(d_res); (void)hipFree(d_sc);
     (void)hipFree(d_sh); (void)hipFree(d_b); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;

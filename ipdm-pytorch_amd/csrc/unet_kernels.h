@@ -55,6 +55,10 @@ struct ConvArgs {
     // w_up2; when conv_up2_eligible(args) the launcher takes this path and writes `out` PARITY-PLANAR:
     // [n][cout][row & 1][col & 1][Ho/2][Wo/2] (same channel stride as NCHW).  Readers set x1_planar (conv_planar_ok).
     const float *w_up2 = nullptr;
+    // ... and, for the layers conv_wup2_shape_ok accepts, the parity filters in the Winograd F(2x2,2x2) domain
+    // (conv_pack_weights_wup2): 9 instead of 16 multiply-adds per 2x2 outputs of a parity, same parity-planar output and
+    // statistics rows (conv_wup2.hip; conv_wup2_eligible).
+    const float *w_wup2 = nullptr;
     // The same layer's weights in the Winograd F(2x2,3x3) domain (conv_pack_weights_wino: U = G g G^T); when
     // conv_wino_eligible(args) the launcher evaluates the convolution there (conv_wino.hip): 16 instead of 36
     // multiply-adds per 2x2 outputs, same NCHW output and statistics rows as the direct kernel.
@@ -118,6 +122,11 @@ constexpr int SPLIT_PIX = 2048;                    // pixels per workgroup (= pe
 int conv_ws_stats_rows(const ConvArgs &a);
 bool conv_up2_eligible(const ConvArgs &a);         // shape fields + w_up2 + w_interleave decide (dry runs included)
 bool conv_wino_eligible(const ConvArgs &a);        // shape fields + w_wino decide
+bool conv_wup2_shape_ok(int Cout, int Cin);        // worth packing the F(2x2,2x2) image of an Upsample layer
+bool conv_wup2_eligible(const ConvArgs &a);        // conv_up2_eligible + w_wup2 + that shape rule (the layer alone)
+int conv2d_wup2_launch(const ConvArgs &orig, hipStream_t st, int prof_cls);   // conv_wup2.hip; called by conv2d_ws_launch
+// [Cin/8][Cout/128][a][b][cout quarter][position 9][k parity][cout 32][k step]
+void conv_pack_weights_wup2(const float *w, int Cout, int Cin, std::vector<float> &packed);
 bool conv_wino_shape_ok(int Cout, int Cin, int ks, int stride, int interleave);   // worth packing U for this layer
 int conv2d_wino_launch(const ConvArgs &a, hipStream_t st);
 int conv_wino_split(const ConvArgs &a);            // K slices conv_wino2 would cut a K-split layer into (0: it cannot)

@@ -1106,7 +1106,9 @@ def _up_conv_chain(case):
               groups, _lib.ptr(arrs[2]), _lib.ptr(arrs[3]), act, _lib.ptr(arrs[4]), _lib.ptr(arrs[5]), CB, ksB, _lib.ptr(d_mid),
               _lib.ptr(d_out), ctypes.byref(used), _lib.current_stream())
     wide_mfma = _lib.lib().ipdm_conv_layout_code(CA, 3, 1) in (2, 4)
-    assert used.value == (1 if wide_mfma else (2 if 4 < CA <= 16 else 0)), used.value
+    # 3: the F(2x2,2x2) form of the parity convolutions (conv_wup2.hip: whole 128-cout tiles, 16-channel chunks)
+    wup2 = wide_mfma and CA % 128 == 0 and C % 16 == 0 and C >= 32 and not _lib.get_option("conv_no_wup2")
+    assert used.value == (3 if wup2 else 1 if wide_mfma else (2 if 4 < CA <= 16 else 0)), used.value
     assert (d_mid.cpu() - mid).abs().max() <= 2e-5 * max(1.0, mid.abs().max().item())
     err = (d_out.cpu() - want).abs().max().item()
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
