@@ -345,9 +345,11 @@ __global__ void __launch_bounds__(512) conv_wup2_kernel(ConvArgs a, int nitems)
                     "v_permlane16_swap_b32 %0, %1\n\t"
                     "v_permlane16_swap_b32 %2, %3"
                     : "+v"(ya0), "+v"(yb0), "+v"(ya1), "+v"(yb1));
-                f32x4 v = {ya0, ya1, yb0, yb1};
+                // (four scalars, not a vector indexed element by element: this compiler stored component 0 of such a vector for
+                //  every element of the ragged run below -- tools/experiments/dbg_up2.py, NOTEBOOK.md round 5)
+                float v[4] = {ya0, ya1, yb0, yb1};
                 const int so = so0 + (8 * g + uu) * plane4;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff4[u], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), o_rsrc, voff4[u], so, 0);
                 if (ragged) {            // (wave-uniform) the run that straddles the edge: element by element, by its lane
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {

@@ -1066,6 +1066,12 @@ UP2_CASES = [
     (1, 64, 34, 50, 64, 64, 64, 3, 1),            # ... GroupNorm without SiLU, 68x100
     (2, 128, 24, 40, 128, 128, 128, 1, 1),        # pointwise kernel reading cat(parity-planar, NCHW skip) with GroupNorm (48x80)
     (1, 128, 27, 45, 128, 0, 256, 1, 0),          # ... a parity-planar source alone, ragged last item (54x90 = 4860 pixels)
+    # the F(2x2,2x2) form's ragged right edge with 2 and 3 pixels of a 4-pixel run inside (1: the 45-column cases above), fused
+    # statistics over several tile columns and clipped tile rows; two cout tiles
+    (1, 128, 9, 34, 128, 0, 128, 3, 2),
+    (2, 128, 7, 39, 128, 0, 128, 3, 2),
+    (1, 256, 10, 70, 256, 0, 128, 3, 1),
+    (1, 128, 114, 250, 128, 0, 128, 1, 2),        # production size (sinogram level 250x114 -> 500x228), 2 pixels of the last run inside
 ]
 
 
