@@ -429,9 +429,11 @@ def main():
                        "weights": "random-init reference architectures (29.1M img / 28.4M proj params)",
                        "work_per_slice": "85.1 TFLOP as the reference evaluates it.  Executed here: the Upsample layers (nearest 2x + "
                                          "3x3 conv) as four 2x2-tap parity convolutions over pre-added weights (4 of 9 multiply-adds per "
-                                         "output: " + ("on" if _lib_option("conv_no_up2") == 0 else "OFF") + "), the wide 3x3 stride-1 "
+                                         "output: " + ("on" if _lib_option("conv_no_up2") == 0 else "OFF") + "), those of the wide levels "
+                                         "in the Winograd F(2x2,2x2) domain (2.25 of 9: " +
+                                         ("on" if _lib_option("conv_no_wup2") == 0 else "OFF") + "), the wide 3x3 stride-1 "
                                          "convolutions in the Winograd F(2x2,3x3) domain (16 of 36: " +
-                                         ("on" if _lib_option("conv_no_wino") == 0 else "OFF") + ") -- both the same functions in exact "
+                                         ("on" if _lib_option("conv_no_wino") == 0 else "OFF") + ") -- all the same functions in exact "
                                          "arithmetic; the value counts slices, roofline.achieved counts EXECUTED flops only"},
             "roofline": roofline, "roofline_hbm": extra.pop("roofline_hbm", None),
             "roofline_narrow_readers": extra.pop("roofline_narrow_readers", None), "kernels": extra,

@@ -203,8 +203,9 @@ int ipdm_op_conv_gn_conv(const float *d_x, int32_t C, int32_t B, int32_t H, int3
                          int32_t *fused_rows, void *stream);
 /* Test entry for the Upsample layer (Model/model.py Upsample: F.interpolate(scale 2, "nearest") + 3x3 conv) in the form the
  * executor runs it: conv A over the 2x up-sampled d_x [B,C,Hs,Ws] (on wide layers as four 2x2-tap parity convolutions over
- * the source grid with pre-added weights, output stored parity-planar: *used_up2 = 1; on narrow layers the same form inside
- * the direct kernel, NCHW output: 2; else the 3x3 form over nearest addressing: 0), then
+ * the source grid with pre-added weights, output stored parity-planar: *used_up2 = 1, or 3 when those four convolutions run
+ * in the Winograd F(2x2,2x2) domain (conv_wup2: whole 128-cout tiles, 16-channel chunks); on narrow layers the parity form
+ * inside the direct kernel, NCHW output: 2; else the 3x3 form over nearest addressing: 0), then
  * GroupNorm(+SiLU) over cat(mid, d_skip) and conv B (ksB = 1 or 3) reading mid as stored.
  *   wA_host [CA,C,3,3], wB_host [CB,CA+C2,ksB,ksB], gamma/beta [CA+C2] HOST; d_skip [B,C2,2Hs,2Ws] or NULL (C2 = 0);
  *   d_mid [B,CA,2Hs,2Ws] (conv A's output as NCHW), d_out [B,CB,2Hs,2Ws]; act: 1 GN, 2 GN+SiLU. */
@@ -293,6 +294,7 @@ int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
  *   7 = parity form of an Upsample (never for this plain shape)   8 = conv_igemm (the generic 4-wave kernel)
  *   9 = conv_wino2 with K slices + combine pass (the layers with too few tiles per sample)
  *   10 = conv_pw (wide 1x1 layers: the barrier-free pointwise kernel)
+ *   11 = conv_wup2 (an Upsample's parity form in the Winograd F(2x2,2x2) domain; never for this plain shape)
  *   -1 = bad argument.
  * Test aid (replaces nothing in the reference): a parity test asserts the kernel it believes it covers. */
 int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W);

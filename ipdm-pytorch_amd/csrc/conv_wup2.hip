@@ -38,7 +38,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef IPDM_WUP2_KO
 #define IPDM_WUP2_KO 0              // compile-time timing knock-outs (results are WRONG): 2 no input transform, 4 no output transform / stores,
-#endif                              // 8 no window loads, 16 no U loads
+#endif                              // 8 no window loads, 16 no U loads, 32 output transform kept but no stores / statistics, 64 no statistics
 
 namespace {
 
@@ -298,7 +298,16 @@ __global__ void __launch_bounds__(512) conv_wup2_kernel(ConvArgs a, int nitems)
         chunk(std::true_type{}, 0);
         for (int ch = 1; ch < nchunks; ++ch) chunk(std::false_type{}, ch);
         // ---------------------------------------------------------------- item epilogue
-        if (IPDM_WUP2_KO & 4) { cur = ItemId{g_n, g_oy, g_ox, g_co * BN, g_a}; continue; }
+        if (IPDM_WUP2_KO & 4) {      // (timing only: one dword per lane keeps the accumulators alive)
+            float ks = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 9; ++e)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ks += acc[e][r];
+            a.out[(size_t)blockIdx.x * 512 + tid] = ks;
+            cur = ItemId{g_n, g_oy, g_ox, g_co * BN, g_a};
+            continue;
+        }
         // + bias through position (1, 1), whose products go to all four outputs with coefficient 1
         acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb, 1.0f, acc[4], 0, 0, 0);
         if (k + 1 < n_my) fetch_bias(g_co * BN);            // (describe(k + 1) ran two chunks ago)
@@ -325,6 +334,7 @@ __global__ void __launch_bounds__(512) conv_wup2_kernel(ConvArgs a, int nitems)
             part[u] = ragged && rok[u] && nval > 0 && nval < 4;
         }
         float *sb = xw;                                      // statistics staging: the wave's scratch is idle here
+        f32x4 ko_sum = {0.0f, 0.0f, 0.0f, 0.0f};
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -349,6 +359,11 @@ __global__ void __launch_bounds__(512) conv_wup2_kernel(ConvArgs a, int nitems)
                 //  every element of the ragged run below -- tools/experiments/dbg_up2.py, NOTEBOOK.md round 5)
                 float v[4] = {ya0, ya1, yb0, yb1};
                 const int so = so0 + (8 * g + uu) * plane4;
+                if (IPDM_WUP2_KO & 32) {      // (timing only: ONE store per item, of the sum of all results, keeps the transform alive)
+                    ko_sum += f32x4{v[0], v[1], v[2], v[3]};
+                    if (i == 7 && u == 1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ko_sum), o_rsrc, voff4[u], so, 0);
+                    continue;
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), o_rsrc, voff4[u], so, 0);
                 if (ragged) {            // (wave-uniform) the run that straddles the edge: element by element, by its lane
 #pragma unroll
@@ -358,7 +373,7 @@ __global__ void __launch_bounds__(512) conv_wup2_kernel(ConvArgs a, int nitems)
                         if (part[u]) v[e] = e < nval ? v[e] : 0.0f;
                     }
                 }
-                if (a.stats) {
+                if (a.stats && !(IPDM_WUP2_KO & 64)) {
                     // fused GroupNorm statistics of the output: one row of per-cout {sum, sum of squares} per PLANE ROW and 32-pixel
                     // column block, as conv_ws.hip's parity form writes them; the 8 lanes of one patch row in a DPP row share a cout
                     float s1 = (v[0] + v[1]) + (v[2] + v[3]);

@@ -1366,9 +1366,14 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     a.Ho = Ho; a.Wo = Wo; a.act = act; a.gn_scale = d_sc; a.gn_shift = d_sh; a.res = d_res; a.out = d_out;
     a.tiles_x = a.tiles_y = a.co_tiles = 0;
     if (x1_planar) { IPDM_REQUIRE(conv_planar_ok(a), "bench_conv2d: this shape has no parity-planar reader"); a.x1_planar = 1; }
-    float *d_split = nullptr;
+    float *d_split = nullptr, *d_stats = nullptr;
     if (conv_split_ws_bytes(a)) IPDM_HIP_CHECK(hipMalloc((void **)&d_split, conv_split_ws_bytes(a)));
     a.split_ws = d_split;
+    if (up && conv_stats_rows(a) > 0) {       // (every Upsample of the networks feeds a GroupNorm: timed with its fused statistics)
+        a.stats_rows = conv_stats_rows(a);
+        IPDM_HIP_CHECK(hipMalloc((void **)&d_stats, (size_t)B * a.stats_rows * Cout * 2 * 4));
+        a.stats = d_stats;
+    }
     int rc = 0;
     const bool stamps = (opt(OPT_CONV_DBG) & 24) != 0;
     if (stamps) { IPDM_HIP_CHECK(hipMalloc((void **)&a.dbg_buf, 4096 * 8 * 8)); IPDM_HIP_CHECK(hipMemset(a.dbg_buf, 0, 4096 * 8 * 8)); }
@@ -1395,7 +1400,7 @@ extern "C" int ipdm_bench_conv2d(int32_t B, int32_t C1, int32_t C2, int32_t H, i
     }
     (void)hipFree(d_split);
     (void)hipFree(d_wino);
-    (void)hipFree(d_wU); (void)hipFree(d_wW);
+    (void)hipFree(d_wU); (void)hipFree(d_wW); (void)hipFree(d_stats);
     (void)hipFree(d_w); (void)hipFree(d_x1); (void)hipFree(d_x2); (void)hipFree(d_out); (void)hipFree(d_res); (void)hipFree(d_sc);
     (void)hipFree(d_sh); (void)hipFree(d_b); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;

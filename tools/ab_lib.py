@@ -25,7 +25,11 @@ if os.environ.get("AB_PW"):          # the layers of the pointwise kernel (conv_
     CONVS = [(8, 256, 0, 57, 125, 768, 1, 1, 1, 0), (8, 128, 128, 228, 500, 128, 1, 1, 0, 0), (8, 256, 0, 57, 125, 256, 1, 1, 0, 1),
              (8, 256, 0, 64, 64, 768, 1, 1, 1, 0), (8, 128, 128, 256, 256, 128, 1, 1, 0, 0), (8, 256, 256, 57, 125, 256, 1, 1, 0, 0),
              (1, 128, 128, 228, 500, 128, 1, 1, 0, 0)]
-ATTN = [] if os.environ.get("AB_WINO") or os.environ.get("AB_PW") else [(8, 4, 64, 7125), (8, 4, 64, 4096), (8, 4, 64, 1827), (8, 4, 64, 1024), (1, 4, 64, 4096)]
+if os.environ.get("AB_UP2"):         # the wide Upsample layers (conv_wup2 / the 2x2-tap parity form; H x W = the SOURCE, act 512 = Upsample mode)
+    CONVS = [(8, 128, 0, 256, 256, 128, 3, 1, 512, 0), (8, 128, 0, 228, 500, 128, 3, 1, 512, 0), (8, 128, 0, 114, 250, 128, 3, 1, 512, 0),
+             (8, 256, 0, 64, 64, 256, 3, 1, 512, 0), (8, 256, 0, 57, 125, 256, 3, 1, 512, 0), (1, 128, 0, 228, 500, 128, 3, 1, 512, 0),
+             (1, 256, 0, 64, 64, 256, 3, 1, 512, 0)]
+ATTN = [] if os.environ.get("AB_WINO") or os.environ.get("AB_PW") or os.environ.get("AB_UP2") else [(8, 4, 64, 7125), (8, 4, 64, 4096), (8, 4, 64, 1827), (8, 4, 64, 1024), (1, 4, 64, 4096)]
 for l in libs:
     l.ipdm_bench_attention.argtypes = [C.c_int32] * 5 + [C.POINTER(C.c_float)]
 ms = C.c_float()

@@ -18,7 +18,8 @@ python3 tools/traffic_summary.py $(find $OUT/${TAG}_pmc_step_fetch -name "*.db" 
 cp profiles/${TAG}_traffic.json profiles/${TAG}_hbm_by_kernel.csv $OUT/
 fi
 # matrix-pipe utilisation of two common shapes of the dominant kernel (conv_wino2: 128->128 @512x512, 256->256 @128x128)
-for shape in "8 128 0 512 512 128 3 1 2 1" "8 256 0 128 128 256 3 1 2 1"; do
+# ... and of the F(2x2,2x2) Upsample kernel (conv_wup2: 128 channels, source 228x500; act 512 = the micro-benchmark's Upsample mode)
+for shape in "8 128 0 512 512 128 3 1 2 1" "8 256 0 128 128 256 3 1 2 1" "8 128 0 228 500 128 3 1 512 0"; do
   name=$(echo $shape | tr ' ' '_')
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU --kernel-trace -d $OUT/${TAG}_pmc_sq_$name -o c -- python3 tools/one_conv.py $shape > /dev/null 2>&1
   python3 tools/rocpd_summary.py $(find $OUT/${TAG}_pmc_sq_$name -name "*.db" | head -1) $OUT/${TAG}_pmc_sq_$name

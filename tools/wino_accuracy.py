@@ -3,7 +3,8 @@
 F(3x3,3x3)): the float32 error of Winograd F(m x m,3x3) for several point sets against a float64 direct convolution, relative
 to the error of a float32 DIRECT convolution, on one 128 -> 128 layer of SiLU-of-normal activations.  U = G g G^T is formed
 in float64 and rounded once (as conv_pack_weights_wino does); V = B^T d B, the channel sum and A^T M A run in float32.
-The gate: rms <= 2x the direct kernel's.   python tools/wino_accuracy.py   (profiles/r05_wino_accuracy.txt)"""
+The gate: rms <= 2x the direct kernel's.   python tools/wino_accuracy.py [--up2]   (profiles/r05_wino_accuracy.txt;
+--up2: the Upsample layer's three forms, round 5)"""
 import numpy as np
 
 
@@ -80,7 +81,92 @@ def direct(x, w, dt):
     return out
 
 
+def upsample_forms():
+    """The Upsample layer (nearest 2x + 3x3) three ways in float32 against float64: the 3x3 form on the up-sampled image, the four
+    2x2-tap parity convolutions (conv_ws.hip), and those in the Winograd F(2x2,2x2) domain (conv_wup2.hip).   --up2"""
+    rng = np.random.default_rng(7)
+    C = K = 128; H = W = 24
+    x = rng.standard_normal((C, H, W)).astype(np.float32)      # an Upsample's input is a ResidualBlock output (no activation)
+    w = (rng.standard_normal((K, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+
+    def direct3x3_up(x, w, dt):
+        xu = np.repeat(np.repeat(x, 2, 1), 2, 2)
+        Cc, Hh, Ww = xu.shape
+        xp = np.pad(xu, ((0, 0), (1, 1), (1, 1))).astype(dt)
+        out = np.zeros((w.shape[0], Hh, Ww), dtype=dt); wd = w.astype(dt)
+        for c in range(Cc):
+            for a in range(3):
+                for b in range(3):
+                    out += wd[:, c, a, b][:, None, None] * xp[c, a:a + Hh, b:b + Ww][None]
+        return out
+
+    def par_w(w):        # [a][b][K][C][2][2] in double
+        w = w.astype(np.float64)
+        rows = {0: [[0], [1, 2]], 1: [[0, 1], [2]]}
+        out = np.zeros((2, 2) + w.shape[:2] + (2, 2))
+        for a in range(2):
+            for b in range(2):
+                for i in range(2):
+                    for j in range(2):
+                        out[a, b, :, :, i, j] = sum(w[:, :, ky, kx] for ky in rows[a][i] for kx in rows[b][j])
+        return out
+
+    def parity_direct(x, w, dt):
+        pw = par_w(w).astype(dt)
+        Cc, Hh, Ww = x.shape
+        xp = np.pad(x, ((0, 0), (1, 1), (1, 1))).astype(dt)
+        out = np.zeros((w.shape[0], 2 * Hh, 2 * Ww), dtype=dt)
+        for a in range(2):
+            for b in range(2):
+                o = np.zeros((w.shape[0], Hh, Ww), dtype=dt)
+                for c in range(Cc):
+                    for i in range(2):
+                        for j in range(2):
+                            o += pw[a, b, :, c, i, j][:, None, None] * xp[c, a + i: a + i + Hh, b + j: b + j + Ww][None]
+                out[:, a::2, b::2] = o
+        return out
+
+    def parity_wino22(x, w, dt):
+        # F(2,2): m1 = (d0 - d1) g0, m2 = d1 (g0 + g1), m3 = (d2 - d1) g1; y0 = m1 + m2, y1 = m2 + m3
+        pw = par_w(w)                                           # double
+        G = np.array([[1, 0], [1, 1], [0, 1]], dtype=np.float64)
+        BT = np.array([[1, -1, 0], [0, 1, 0], [0, -1, 1]], dtype=np.float64)
+        AT = np.array([[1, 1, 0], [0, 1, 1]], dtype=np.float64)
+        Cc, Hh, Ww = x.shape
+        xp = np.pad(x, ((0, 0), (1, 1), (1, 1))).astype(dt)
+        out = np.zeros((w.shape[0], 2 * Hh, 2 * Ww), dtype=dt)
+        for a in range(2):
+            for b in range(2):
+                U = np.einsum("pi,kcij,qj->pqkc", G, pw[a, b], G).astype(dt)      # rounded once
+                o = np.zeros((w.shape[0], Hh, Ww), dtype=dt)
+                for ty in range(Hh // 2):
+                    d = np.stack([xp[:, a + 2 * ty: a + 2 * ty + 3, b + 2 * tx: b + 2 * tx + 3] for tx in range(Ww // 2)], 0)
+                    V = np.einsum("pi,tcij,qj->pqtc", BT.astype(dt), d, BT.astype(dt)).astype(dt)
+                    M = np.zeros((3, 3, Ww // 2, w.shape[0]), dtype=dt)
+                    for c in range(Cc):
+                        M += V[:, :, :, c, None] * U[:, :, None, :, c]
+                    Y = np.einsum("up,pqtk,vq->tkuv", AT.astype(dt), M, AT.astype(dt)).astype(dt)
+                    for tx in range(Ww // 2):
+                        o[:, 2 * ty: 2 * ty + 2, 2 * tx: 2 * tx + 2] = Y[tx]
+                out[:, a::2, b::2] = o
+        return out
+
+    ref = direct3x3_up(x, w, np.float64)
+    assert np.abs(parity_direct(x, w, np.float64) - ref).max() < 1e-12
+    assert np.abs(parity_wino22(x, w, np.float64) - ref).max() < 1e-12
+    rows = [("direct 3x3 on the up-sampled image, f32", direct3x3_up(x, w, np.float32) - ref),
+            ("parity form, four 2x2-tap convolutions, f32 (shipped)", parity_direct(x, w, np.float32) - ref),
+            ("parity form in F(2x2,2x2), f32", parity_wino22(x, w, np.float32) - ref)]
+    base, bmax = np.sqrt((rows[0][1] ** 2).mean()), np.abs(rows[0][1]).max()
+    for name, e in rows:
+        print("%-56s rms %.3e  max %.3e   rms / direct %.2f   max / direct %.2f" % (name, np.sqrt((e ** 2).mean()), np.abs(e).max(), np.sqrt((e ** 2).mean()) / base, np.abs(e).max() / bmax))
+
+
 if __name__ == "__main__":
+    import sys
+    if "--up2" in sys.argv:
+        upsample_forms()
+        sys.exit(0)
     rng = np.random.default_rng(7)
     C = K = 128
     H = W = 48
