@@ -81,6 +81,30 @@ def direct(x, w, dt):
     return out
 
 
+def winograd_mixed(x, w, mr, mc, dt):
+    """F(m_r x m_c, 3x3) with different tiles along rows and columns (round 5: F(2,3) x F(3,3), 20 products per 6 outputs)."""
+    ATr, Gr, BTr = mr
+    ATc, Gc, BTc = mc
+    m_r, n_r = ATr.shape
+    m_c, n_c = ATc.shape
+    C, H, W = x.shape
+    K = w.shape[0]
+    U = np.einsum("ia,kcab,jb->ijkc", Gr, w.astype(np.float64), Gc).astype(dt)
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1))).astype(dt)
+    th, tw = H // m_r, W // m_c
+    out = np.zeros((K, H, W), dtype=dt)
+    for ty in range(th):
+        d = np.stack([xp[:, ty * m_r: ty * m_r + n_r, tx * m_c: tx * m_c + n_c] for tx in range(tw)], 0)
+        V = np.einsum("ia,tcab,jb->ijtc", BTr.astype(dt), d, BTc.astype(dt)).astype(dt)
+        M = np.zeros((n_r, n_c, tw, K), dtype=dt)
+        for c in range(C):
+            M += V[:, :, :, c, None] * U[:, :, None, :, c]
+        Y = np.einsum("ia,abtk,jb->tkij", ATr.astype(dt), M, ATc.astype(dt)).astype(dt)
+        for tx in range(tw):
+            out[:, ty * m_r:(ty + 1) * m_r, tx * m_c:(tx + 1) * m_c] = Y[tx]
+    return out
+
+
 def upsample_forms():
     """The Upsample layer (nearest 2x + 3x3) three ways in float32 against float64: the 3x3 form on the up-sampled image, the four
     2x2-tap parity convolutions (conv_ws.hip), and those in the Winograd F(2x2,2x2) domain (conv_wup2.hip).   --up2"""
@@ -189,6 +213,9 @@ if __name__ == "__main__":
         e = winograd(x, w, AT, G, BT, np.float32).astype(np.float64) - ref
         rows.append((name, e))
     base, bmax = np.sqrt((rows[0][1] ** 2).mean()), np.abs(rows[0][1]).max()
+    m2 = mats([0, 1, -1])
+    for name, pts in (("F(2x3,3x3) points 0, 1, -1 | 0, 1, -1, 2", [0, 1, -1, 2]), ("F(2x3,3x3) points 0, 1, -1 | 0, 1, -1, 1/2", [0, 1, -1, 0.5])):
+        rows.append((name, winograd_mixed(x, w, m2, mats(pts), np.float32).astype(np.float64) - ref))
     for name, e in rows:
         print("%-42s rms %.3e  max %.3e   rms / direct %.2f   max / direct %.2f" % (
             name, np.sqrt((e ** 2).mean()), np.abs(e).max(), np.sqrt((e ** 2).mean()) / base, np.abs(e).max() / bmax))
