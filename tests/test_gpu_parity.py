@@ -1126,6 +1126,26 @@ def test_upsample_conv_parity_form(case):
     _up_conv_chain(case)
 
 
+def test_upsample_winograd_form_against_the_2x2_tap_form():
+    """conv_wup2 (the four parity convolutions in the Winograd F(2x2,2x2) domain) and conv_ws's 2x2-tap parity kernel are the same
+    function in exact arithmetic: both within the tolerance of the torch reference (inside _up_conv_chain, which also asserts which
+    kernel ran) and within float32 rounding of each other, fused statistics and every edge kind included."""
+    from ipdm_pytorch_amd import _lib
+    n = 0
+    for case in UP2_CASES:
+        B, C, Hs, Ws, CA = case[:5]
+        if CA % 128 or C % 16 or C < 32:
+            continue
+        mid, out = _up_conv_chain(case)
+        with _lib.option("conv_no_wup2", 1):
+            mid0, out0 = _up_conv_chain(case)
+        assert not torch.equal(mid, mid0)          # (another summation order: the option really switches kernels)
+        assert (mid - mid0).abs().max() <= 1.5e-5 * max(1.0, mid0.abs().max().item()), case
+        assert (out - out0).abs().max() <= 1.5e-5 * max(1.0, out0.abs().max().item()), case
+        n += 1
+    assert n >= 8
+
+
 def test_fused_statistics_equal_activation_pass():
     """The two ways of forming GroupNorm statistics (fused per-tile partial sums / option gn_unfused: a pass over the
     activations) agree to float32 rounding through a whole small UNet, concat inputs and materialised concats included."""
