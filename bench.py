@@ -376,8 +376,11 @@ def main():
                         "avg_launch_gflop": round(fl[dom] / nl[dom] / 1e9, 3)}
             if dom in (3, 5):
                 roofline["reference_form_tflops"] = round(ach * 36.0 / 16.0, 2)     # the same launches counted as 3x3 convolutions
-        names = {5: "conv3x3_winograd_128cout_tiles", 3: "conv3x3_winograd_64cout_tiles", 0: "conv3x3_direct_form", 1: "conv_other", 2: "attention"}      # (4, 6: roofline_hbm / roofline_narrow_readers)
-        for c in (5, 3, 0, 1, 2):
+        names = {5: "conv3x3_winograd_128cout_tiles", 3: "conv3x3_winograd_64cout_tiles", 0: "conv3x3_direct_form", 1: "conv_other", 2: "attention",
+                 7: "upsample_winograd_f2x2_2x2"}      # (4, 6: roofline_hbm / roofline_narrow_readers)
+        for c in (5, 3, 0, 1, 2, 7):
+            if c >= NC:
+                continue
             name = names[c]
             if c == dom:
                 continue

@@ -31,7 +31,7 @@ extern "C" {
 #define IPDM_ERR_UNSUPPORTED (-4)
 
 const char *ipdm_last_error(void);
-/* ABI version of this header (bumped on any signature change or new entry point): 4. */
+/* ABI version of this header (bumped on any signature change or new entry point): 5. */
 int ipdm_abi_version(void);
 
 /* Process-wide switches of the library (A/B experiments, opt-in evaluation modes); no reference counterpart -- the
@@ -263,10 +263,11 @@ int ipdm_art_project(ipdm_art_plan *plan, const float *d_volume, float *d_proj, 
  * (bandwidth-bound: `out_flops[4]` holds their algorithmic HBM BYTES), 5 = the 128-cout-tile Winograd kernel
  * (conv_wino2, the dominant kernel; class 3 keeps the 64-cout-tile one), 6 = the narrow direct convolutions that read a
  * wide tensor (>= 64 input channels: bound by the f32 vector ALU, recorded with their flops; class 4 keeps the
- * bandwidth-bound ones).  ipdm_profile_end needs the stream
+ * bandwidth-bound ones), 7 = the wide Upsample layers in the Winograd F(2x2,2x2) domain of their parity form (conv_wup2;
+ * executed flops: 9 products per source pixel and channel pair).  ipdm_profile_end needs the stream
  * synchronised; outputs are arrays of `n_classes` >= IPDM_PROF_CLASSES entries (a shorter array is an error, not an
  * overflow). */
-#define IPDM_PROF_CLASSES 7
+#define IPDM_PROF_CLASSES 8
 int ipdm_profile_begin(int32_t max_launches);
 /* ... recording only the classes whose bit is set in class_mask (an event pair costs the stream about a microsecond per
  * launch: bench.py times its headline with the dominant kernel's classes only and the rest on an extra, untimed pass) */

@@ -31,8 +31,8 @@ class UnetCfg(C.Structure):
 _vp, _i32, _i64, _u64, _f32, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); restype int => status code checked by _call
-ABI_VERSION = 4          # ipdm_abi_version() of the header these prototypes were written against
-PROF_CLASSES = 7         # kernel classes of ipdm_profile_end (include/ipdm_hip.h)
+ABI_VERSION = 5          # ipdm_abi_version() of the header these prototypes were written against
+PROF_CLASSES = 8         # kernel classes of ipdm_profile_end (include/ipdm_hip.h)
 
 PROTOTYPES = {
     "ipdm_last_error": (C.c_char_p, []),

@@ -790,7 +790,7 @@ static int conv2d_ws_dispatch(const ConvArgs &a, hipStream_t st);
 int conv2d_ws_launch(const ConvArgs &a, hipStream_t st)
 {
     if (conv_up2_eligible(a)) {
-        if (conv_wup2_eligible(a)) return conv2d_wup2_launch(a, st, 1);      // the F(2x2,2x2) form of the same four convolutions
+        if (conv_wup2_eligible(a)) return conv2d_wup2_launch(a, st, 7);      // the F(2x2,2x2) form of the same four convolutions
         ConvArgs k = a;
         k.up2 = 1; k.w = a.w_up2; k.ksize = 2; k.upsample = 0; k.H = k.Ho = a.Hs; k.W = k.Wo = a.Ws; k.split_ws = nullptr; k.ksplit = 1;
         // (16-channel chunks -- 16k instead of 8k cycles of MFMA per hand-over -- measured 0.7 % slower per forward)

@@ -91,7 +91,8 @@ int conv_ws_k_chunk(int ks, int interleave);   // K chunk of the kernel a (ks, w
 // 4 = the narrow direct convolutions (conv_direct.hip), bandwidth-bound: recorded with their algorithmic HBM BYTES
 // 5 = the 128-cout-tile Winograd kernel (conv_wino2.hip; class 3 keeps the 64-cout-tile kernel), EXECUTED flops
 // 6 = the narrow direct convolutions that READ a wide tensor (>= 64 input channels): f32-VALU-bound, recorded with their flops
-constexpr int PROF_CLASSES = 7;
+// 7 = the wide Upsample layers in the Winograd F(2x2,2x2) domain of their parity form (conv_wup2.hip), EXECUTED flops (9 products per source pixel)
+constexpr int PROF_CLASSES = 8;
 bool prof_enabled();
 void prof_before(int cls, hipStream_t st);
 void prof_after(int cls, double flops, hipStream_t st);

@@ -41,7 +41,7 @@ def test_host_only_entry_points():
     """Schedule tables and UNet parameter inventory are host code: callable without a GPU."""
     from ipdm_pytorch_amd import _lib
     lib = _lib.lib()
-    assert lib.ipdm_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.ipdm_abi_version() == _lib.ABI_VERSION == 5
     out = C.c_double()
     _lib.call("ipdm_cosine_lambda", 15, 1.0, 3, C.byref(out))
     assert 0.0 <= out.value <= 0.999

@@ -936,6 +936,15 @@ def test_profile_classes_mask():
     assert nl[1] == 1 and sum(nl) == 1
     nl, _, _ = run((1 << 5) | (1 << 3) | (1 << 0))
     assert nl[5] == 1 and sum(nl) == 1
+    # a wide Upsample layer is class 7 (conv_wup2: executed flops = 9 products per source pixel), class 1 on the 2x2-tap kernel
+    for off, cls, taps in ((0, 7, 9), (1, 1, 16)):
+        with _lib.option("conv_no_wup2", off):
+            _lib.call("ipdm_profile_begin", 64)
+            _up_conv_chain((2, 128, 16, 32, 128, 0, 128, 3, 2))
+            torch.cuda.synchronize()
+            fl, ms, nl = (C.c_double * NC)(), (C.c_double * NC)(), (C.c_int64 * NC)()
+            _lib.call("ipdm_profile_end", C.byref(fl), C.byref(ms), C.byref(nl), NC)
+        assert nl[cls] == 1 and fl[cls] == 2.0 * 2 * 16 * 32 * 128 * 128 * taps, (off, list(nl), list(fl))
     fl, ms, nl = (C.c_double * NC)(), (C.c_double * NC)(), (C.c_int64 * NC)()
     _lib.call("ipdm_profile_begin", 8)
     with pytest.raises(RuntimeError):          # the caller states its array length: one shorter than the class count is refused
