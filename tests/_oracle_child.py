@@ -24,17 +24,18 @@ SMOKE_PROJ = dict(in_channels=1, model_channels=16, out_channels=1, attention_re
 SMOKE_IMG = dict(in_channels=1, model_channels=16, out_channels=1, attention_resolutions=(8,), channel_mult=(1, 1, 2, 2, 4), num_heads=1)
 
 
-def write_job(path, opt_dict, sino, draws, weight_seed, sharpen_num, dtype="float32", nets="full"):
+def write_job(path, opt_dict, sino, draws, weight_seed, sharpen_num, dtype="float32", nets="full", mid=False):
     """draws: the recorded [1,1,h,w] tensors/arrays of ONE slice, in order (sinogram-shaped ones first, then image-shaped).
     dtype "float64": the ARBITER run -- the same float32 inputs, weights and draws evaluated in double precision.
     nets "full": the production architectures, both with synthetic weights of seed `weight_seed`; "smoke": the reduced
-    16-channel networks of ipdm_pytorch_amd.denoiser.SMOKE_PROJ / SMOKE_IMG with weight seeds (weight_seed, weight_seed + 1)."""
+    16-channel networks of ipdm_pytorch_amd.denoiser.SMOKE_PROJ / SMOKE_IMG with weight seeds (weight_seed, weight_seed + 1).
+    mid: the child saves every stored iterate too (out.npy -> out.npy + out.npy.mid.npz: proj [n,h,w], fbp [G,G], img [m,G,G])."""
     import numpy as np
     draws = [np.asarray(d, dtype=np.float32).reshape(d.shape[-2], d.shape[-1]) for d in draws]
     n_p = sum(1 for d in draws if d.shape == tuple(sino.shape))
     assert all(d.shape == tuple(sino.shape) for d in draws[:n_p]) and all(d.shape != tuple(sino.shape) for d in draws[n_p:])
     np.savez(path, sino=np.asarray(sino, dtype=np.float32), draws_p=np.stack(draws[:n_p]), draws_i=np.stack(draws[n_p:]),
-             opt=json.dumps({k: opt_dict[k] for k in OPT_KEYS}), weight_seed=weight_seed, sharpen_num=sharpen_num, dtype=dtype, nets=nets)
+             opt=json.dumps({k: opt_dict[k] for k in OPT_KEYS}), weight_seed=weight_seed, sharpen_num=sharpen_num, dtype=dtype, nets=nets, mid=int(bool(mid)))
 
 
 def cpu_blocks(njobs, threads):
@@ -85,9 +86,12 @@ def main():
     sd_p = {k: torch.from_numpy(v).to(dt) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_p), seed=seed).items()}
     sd_i = {k: torch.from_numpy(v).to(dt) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_i), seed=seed + (1 if smoke else 0)).items()}
     draws = iter([torch.from_numpy(d)[None, None].to(dt) for d in j["draws_p"]] + [torch.from_numpy(d)[None, None].to(dt) for d in j["draws_i"]])
-    want, _ = op.progressive_slice(opt, cfg_p, sd_p, cfg_i, sd_i, torch.from_numpy(j["sino"])[None, None].to(dt),
+    want, mid = op.progressive_slice(opt, cfg_p, sd_p, cfg_i, sd_i, torch.from_numpy(j["sino"])[None, None].to(dt),
                                    lambda: next(draws), sharpen_num=int(j["sharpen_num"]))
     assert next(draws, None) is None, "the oracle consumed fewer draws than the device recorded"
+    if "mid" in j.files and int(j["mid"]):
+        np.savez(out + ".mid.npz", proj=np.stack([m.numpy()[0, 0] for m in mid["proj"]]), fbp=mid["fbp"].numpy()[0, 0],
+                 img=np.stack([m.numpy()[0, 0] for m in mid["img"]]))
     np.save(out, want.numpy())
 
 

@@ -81,6 +81,12 @@ PIPE_SEEDS = dict(proj_weights=71, img_weights=72, phantom=1, dose=1, noise=73)
 PIPE_SHARPEN = 70
 
 
+# BASELINE.json config C1, literally: one 512x512 slice, image domain only, t_start_img=[5], constant guidance 0.45, no ultra pass
+# (tests/golden/pipeline_c1.npz from the reference harness's img_denoiser(mode="img_only"), PIPE_OPT networks)
+C1_OPT = dict(t_start_img=[5], constant_guidance_img=0.45, ultra_img_denoise=False, save_it_state_img=True)
+C1_NOISE_SEED, C1_INPUT_SEED = 76, 75
+
+
 class hashed_noise:
     """Noise source for the HIP path (next_like) and the oracle (draws(shapes)): draw k = hash_normal(shape of the
     k-th request, seed*1000+k) -- what make_golden's _NoiseFeed hands the reference in place of torch.randn_like."""

@@ -459,6 +459,39 @@ def gen_pipeline_img():
     save("pipeline_img", **out)
 
 
+def gen_pipeline_c1():
+    """BASELINE.json config C1 at its literal setting: ONE 512x512 slice, image domain only, t_start_img=[5],
+    constant_guidance_img=0.45, no ultra pass -- the reference harness's img_denoiser(mode="img_only")
+    (Utils/train_test_utils.py:482-550) on an input regenerable from integer hashes, every stored iterate."""
+    from tests.golden.cases import PIPE_SEEDS, C1_OPT, C1_NOISE_SEED, C1_INPUT_SEED
+    cwd = os.getcwd()
+    os.chdir(ref_shim.REFERENCE_ROOT)
+    orig_randn, orig_loader = torch.randn_like, U.progressive_domain_denoiser.init_data_loader
+    out = {}
+    try:
+        den = _ref_denoiser(dict(C1_OPT, mode="test_img"))
+        x = synth.rasterize(synth.ellipse_phantom(PIPE_SEEDS["phantom"])) + 0.004 * synth.hash_normal((512, 512), C1_INPUT_SEED)
+        feed = _NoiseFeed(C1_NOISE_SEED)
+        torch.randn_like = feed
+        res = den.img_denoiser(torch.from_numpy(x.astype(np.float32))[None, None], noise_strength=None, mode="img_only")
+        out["ndraws"] = np.array(feed.k)
+        out["final_sub4"] = res.numpy()[0, 0, ::4, ::4].copy()
+        out["final_rows"] = res.numpy()[0, 0, 254:258].copy()
+        out["keys"] = np.array(sorted(den.img_denoise_result.keys()))
+        for k in sorted(den.img_denoise_result.keys()):
+            out["img_" + k] = den.img_denoise_result[k][0, 0, ::16, ::16].copy()
+        from Dataset.npz_data_loader import miu2pixel
+        ph = miu2pixel(synth.rasterize(synth.ellipse_phantom(PIPE_SEEDS["phantom"])))
+        mse = float(np.mean((miu2pixel(res.numpy()[0, 0]) - ph) ** 2))
+        out["psnr_vs_phantom"] = np.array(10.0 * np.log10(1.0 / mse))
+        assert len(den.progressive_denoise_result) == 0
+    finally:
+        torch.randn_like = orig_randn
+        U.progressive_domain_denoiser.init_data_loader = orig_loader
+        os.chdir(cwd)
+    save("pipeline_c1", **out)
+
+
 # ------------------------------------------------------------------ 9. ART data tables
 def gen_art_tables():
     """Samples of the two data files the ART convertor is driven by (Recon/Simens_alut.txt: the pixel-area table
@@ -506,6 +539,7 @@ if __name__ == "__main__":
     gen_misc()
     gen_pipeline()
     gen_pipeline_img()
+    gen_pipeline_c1()
     gen_fbp()
     gen_art_tables()
     gen_metrics()

@@ -1403,13 +1403,31 @@ def test_guided_reverse_process_batch_equals_per_slice():
 
 
 # =========================================================================== end to end
-def test_smoke_pipeline_matches_oracle_psnr():
+# The heavy end-to-end tests are PAIRS (tests/_oracle_pool.py, tests/conftest.py): `*_device_run` (oracle_submit, collected
+# first) runs the device side and hands one CPU replay per slice / seed / precision to the session's oracle pool; the verdict
+# test of the same name as in rounds 1-5 (oracle_join, collected last) joins them and asserts.  A verdict test run on its own
+# (-k) performs its device run first.
+def _once(pool, tag, fn):
+    if tag not in pool.stash:
+        pool.stash[tag] = fn(pool)
+    return pool.stash[tag]
+
+
+def _smoke_psnr_submit(pool):
+    from ipdm_pytorch_amd.denoiser import smoke_pipeline
+    from tests import _oracle_child as oc
+    got, inputs = smoke_pipeline(DEV)
+    job = pool.path("smoke_psnr.npz")
+    oc.write_job(job, inputs["opt"], inputs["ldproj"], [z.numpy() for z in inputs["noise"]], 21, 70, nets="smoke")
+    return dict(got=got, h=pool.submit("smoke pipeline f32", job, 8))
+
+
+@pytest.mark.oracle_join
+def test_smoke_pipeline_matches_oracle_psnr(oracle_pool):
     """proj GRP -> FBP -> sharpen -> img GRP -> ultra on a real-geometry phantom sinogram, reduced UNets.
     north_star: PSNR (vs ground truth, on miu2pixel images) within 1e-4 relative of the CPU path."""
-    from ipdm_pytorch_amd.denoiser import smoke_pipeline
-    from oracle import pipeline as op
-    got, inputs = smoke_pipeline(DEV)
-    want = op.smoke_pipeline_oracle(inputs)
+    st = _once(oracle_pool, "smoke_psnr", _smoke_psnr_submit)
+    got, want = st["got"], oracle_pool.result(st["h"])
     assert got.shape == want.shape == (1, 1, 512, 512)
     # Eleven evaluations of random-weight networks amplify float32 rounding ~100x: the float32 CPU oracle itself ends
     # 2.4e-4 (max-abs; rms 3.7e-6) from the float64 value of the same function (test_smoke_pipeline_fp64_arbiter, which
@@ -1424,7 +1442,51 @@ def test_smoke_pipeline_matches_oracle_psnr():
     assert abs(p_hip - p_cpu) <= 1e-4 * abs(p_cpu), (p_hip, p_cpu)
 
 
-def test_smoke_pipeline_fp64_arbiter():
+def _reduced_denoiser(seed, wp, wi, phantom, **over):
+    """The reduced (smoke) networks with weight seeds (wp, wi) behind the drop-in surface, one real-geometry phantom loaded,
+    the device's draws recorded."""
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG, _RecordingNoise
+    from ipdm_pytorch_amd.diffusion import NoiseSource
+    from ipdm_pytorch_amd.unet import UNetModel
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    cfg_load(dict(dict(device=DEV, t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=True), **over), opt.__dict__)
+    den = progressive_domain_denoiser(opt, seed=seed)
+    den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
+    den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
+    den.proj_model.load_state_dict({n: torch.from_numpy(v) for n, v in synth.synth_state_dict(den.proj_model._shapes, seed=wp).items()})
+    den.img_model.load_state_dict({n: torch.from_numpy(v) for n, v in synth.synth_state_dict(den.img_model._shapes, seed=wi).items()})
+    sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(phantom)), seed=phantom)
+    den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
+    den.noise = _RecordingNoise(NoiseSource(seed, 0))
+    return den, opt, sino
+
+
+ARBITER_STAGE_SEEDS = ((11, 21, 1), (29, 102, 2), (43, 104, 3))        # (noise seed, weight seed of the proj net [img: +1], phantom)
+
+
+def _arbiter_stages_submit(pool):
+    from tests import _oracle_child as oc
+    runs = []
+    for seed, wp, ph in ARBITER_STAGE_SEEDS:
+        den, opt, sino = _reduced_denoiser(seed, wp, wp + 1, ph, save_it_state_proj=True, save_it_state_img=True)
+        den.progressive_denoiser(save_proj_state=True, sharpen_num=70)
+        draws = [z.cpu().numpy() for z in den.noise.draws]
+        hs = {}
+        for dt, thr in (("float64", 10), ("float32", 6)):
+            job = pool.path("stage%d_%s.npz" % (seed, dt))
+            oc.write_job(job, opt.__dict__, sino, draws, wp, 70, dtype=dt, nets="smoke", mid=True)
+            hs[dt] = pool.submit("stages seed %d %s" % (seed, dt), job, thr)
+        n_p = len(den.proj_denoise_result)
+        hip = ([np.array(den.proj_denoise_result[j + 1]) for j in range(n_p)], np.array(den.proj_denoise_convert2img_result[n_p]),
+               [np.array(den.progressive_denoise_result[j + 1]) for j in range(len(den.progressive_denoise_result))])
+        runs.append(dict(seed=seed, hip=hip, h=hs))
+    return runs
+
+
+@pytest.mark.oracle_join
+def test_smoke_pipeline_fp64_arbiter(oracle_pool):
     """Who is right when two float32 evaluations differ?  The reduced end-to-end pipeline once more on the CPU in FLOAT64
     (same float32 inputs, weights, draws and schedule constants: oracle.pipeline.progressive_slice on float64 tensors) is
     the value both approximate.  STAGE BY STAGE -- every stored iterate of the projection loop, the FBP image, every iterate of
@@ -1434,49 +1496,16 @@ def test_smoke_pipeline_fp64_arbiter():
     chaotically (round 3: the oracle's own distance moved 2.4x with nothing but its thread count): after it a single seed is
     one draw from that distribution, so each amplified stage is judged by the MEDIAN over the seeds (ARBITER_MEDIAN_*, the
     criterion of test_smoke_pipeline_fp64_arbiter_over_seeds) plus the hard cap on the worst one."""
-    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
-    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG, _RecordingNoise
-    from ipdm_pytorch_amd.diffusion import NoiseSource
-    from ipdm_pytorch_amd.unet import UNetModel
-    from oracle import pipeline as op
-    cfg_p = ou.UNetConfig(1, 16, 1, attention_resolutions=(16,), channel_mult=(0.25, 0.25, 0.5, 1, 2, 4), num_heads=1)
-    cfg_i = ou.UNetConfig(1, 16, 1, attention_resolutions=(8,), channel_mult=(1, 1, 2, 2, 4), num_heads=1)
-
     def dist(a, b):
-        e = np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))
+        e = np.abs(np.asarray(a, dtype=np.float64).reshape(np.asarray(b).shape) - np.asarray(b, dtype=np.float64))
         return float(e.max()), float(np.sqrt((e ** 2).mean()))
     per_stage = {}                       # stage -> [(ratio max-abs, ratio rms, amplified)] over the seeds
-    for k, (seed, wp, wi, ph) in enumerate(((11, 21, 22, 1), (29, 102, 103, 2), (43, 104, 105, 3))):
-        opt = default_cfg([])
-        cfg_load(mayo_test_options(), opt.__dict__)
-        cfg_load(dict(device=DEV, t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=True, save_it_state_proj=True,
-                      save_it_state_img=True), opt.__dict__)
-        den = progressive_domain_denoiser(opt, seed=seed)
-        den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
-        den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
-        sd_p = synth.synth_state_dict(den.proj_model._shapes, seed=wp)
-        sd_i = synth.synth_state_dict(den.img_model._shapes, seed=wi)
-        den.proj_model.load_state_dict({n: torch.from_numpy(v) for n, v in sd_p.items()})
-        den.img_model.load_state_dict({n: torch.from_numpy(v) for n, v in sd_i.items()})
-        sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(ph)), seed=ph)
-        den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
-        rec = _RecordingNoise(NoiseSource(seed, 0))
-        den.noise = rec
-        den.progressive_denoiser(save_proj_state=True, sharpen_num=70)
-        draws = [z.cpu() for z in rec.draws]
-
-        def oracle(dt, threads):
-            torch.set_num_threads(min(threads, os.cpu_count() or threads))
-            it = iter(draws)
-            _, mid = op.progressive_slice(dict(opt.__dict__), cfg_p, {n: torch.from_numpy(v).to(dt) for n, v in sd_p.items()}, cfg_i,
-                                          {n: torch.from_numpy(v).to(dt) for n, v in sd_i.items()},
-                                          torch.from_numpy(sino)[None, None].to(dt), lambda: next(it).to(dt), sharpen_num=70)
-            return ([m.numpy() for m in mid["proj"]], mid["fbp"].numpy(), [m.numpy() for m in mid["img"]])
-        m64 = oracle(torch.float64, 64)
-        m32 = oracle(torch.float32, 32)
+    for k, run in enumerate(_once(oracle_pool, "arbiter_stages", _arbiter_stages_submit)):
+        seed, hip = run["seed"], run["hip"]
+        (_, z64), (_, z32) = oracle_pool.result(run["h"]["float64"], mid=True), oracle_pool.result(run["h"]["float32"], mid=True)
+        m64, m32 = (z64["proj"], z64["fbp"], z64["img"]), (z32["proj"], z32["fbp"], z32["img"])
         n_p, n_i = len(m64[0]), len(m64[2])
-        hip = ([den.proj_denoise_result[j + 1] for j in range(n_p)], den.proj_denoise_convert2img_result[n_p],
-               [den.progressive_denoise_result[j + 1] for j in range(n_i)])
+        assert len(hip[0]) == n_p and len(hip[2]) == n_i
         stages = [("proj iter_%d" % (j + 1), lambda m, j=j: m[0][j]) for j in range(n_p)] + [("fbp", lambda m: m[1])] + \
                  [("img iter_%d" % (j + 1), lambda m, j=j: m[2][j]) for j in range(n_i)]
         for name, pick in stages:
@@ -1494,7 +1523,7 @@ def test_smoke_pipeline_fp64_arbiter():
         if k == 0:
             ff = dist(hip[2][-1], m32[2][-1])
             scale = float(np.abs(m64[2][-1]).max())
-            print("fp64 arbiter: |hip-cpu32(32 threads)| at the end max %.3e rms %.3e (scale %.3f)" % (ff[0], ff[1], scale))
+            print("fp64 arbiter: |hip-cpu32| at the end max %.3e rms %.3e (scale %.3f)" % (ff[0], ff[1], scale))
             assert ff[0] <= E2E_MAX_REL * max(1.0, scale)
     for name, rs in per_stage.items():
         amp = [r for r in rs if r[2]]
@@ -1504,39 +1533,30 @@ def test_smoke_pipeline_fp64_arbiter():
             assert med_rms <= ARBITER_MEDIAN_RMS and med_max <= ARBITER_MEDIAN_MAX, (name, rs)
 
 
-def test_smoke_pipeline_fp64_arbiter_over_seeds(tmp_path):
+def _arbiter_seeds_submit(pool):
+    from tests import _oracle_child as oc
+    hips, h32, h64 = [], [], []
+    for k, seed in enumerate((11, 29, 43, 61, 83, 97, 113)):      # (round 5: two more -- a median of 1.32 under 1.5 on five was thin)
+        wseed = 100 + 2 * k
+        den, opt, sino = _reduced_denoiser(seed, wseed, wseed + 1, k + 1)
+        hips.append(den.progressive_denoiser(sharpen_num=70).cpu().numpy())
+        draws = [z.cpu().numpy() for z in den.noise.draws]
+        for dt, lst, thr in (("float64", h64, 6), ("float32", h32, 4)):
+            job = pool.path("smoke%d_%s.npz" % (seed, dt))
+            oc.write_job(job, opt.__dict__, sino, draws, wseed, 70, dtype=dt, nets="smoke")
+            lst.append(pool.submit("reduced seed %d %s" % (seed, dt), job, thr))
+    return dict(hips=hips, h32=h32, h64=h64)
+
+
+@pytest.mark.oracle_join
+def test_smoke_pipeline_fp64_arbiter_over_seeds(oracle_pool):
     """The fp64 arbiter as a statistic: the reduced end-to-end pipeline (proj loop 2+2 steps, FBP, sharpen, img loop, ultra
     pass) for SEVEN seeds -- network weights, phantom, dose noise and diffusion draws all vary -- each replayed by the CPU
     oracle in float32 and in float64 (pinned child processes).  Median over the seeds of err(HIP, fp64) / err(oracle32,
     fp64) at the END of the chain (after the amplifying image-domain passes): <= 1.25 in rms, <= 1.5 in max-abs."""
-    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
-    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, SMOKE_PROJ, SMOKE_IMG, _RecordingNoise
-    from ipdm_pytorch_amd.diffusion import NoiseSource
-    from ipdm_pytorch_amd.unet import UNetModel
-    from tests import _oracle_child as oc
-    hips, jobs32, jobs64 = [], [], []
-    for k, seed in enumerate((11, 29, 43, 61, 83, 97, 113)):      # (round 5: two more -- a median of 1.32 under 1.5 on five was thin)
-        opt = default_cfg([])
-        cfg_load(mayo_test_options(), opt.__dict__)
-        cfg_load(dict(device=DEV, t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=True), opt.__dict__)
-        den = progressive_domain_denoiser(opt, seed=seed)
-        den.proj_model = UNetModel(**SMOKE_PROJ).to(DEV)
-        den.img_model = UNetModel(**SMOKE_IMG).to(DEV)
-        wseed = 100 + 2 * k
-        den.proj_model.load_state_dict({n: torch.from_numpy(v) for n, v in synth.synth_state_dict(den.proj_model._shapes, seed=wseed).items()})
-        den.img_model.load_state_dict({n: torch.from_numpy(v) for n, v in synth.synth_state_dict(den.img_model._shapes, seed=wseed + 1).items()})
-        sino = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(k + 1)), seed=k + 1)
-        den.data_sample_load(ldproj=torch.from_numpy(sino)[None, None])
-        rec = _RecordingNoise(NoiseSource(seed, 0))
-        den.noise = rec
-        hips.append(den.progressive_denoiser(sharpen_num=70).cpu().numpy())
-        draws = [z.cpu().numpy() for z in rec.draws]
-        for dt, lst in (("float32", jobs32), ("float64", jobs64)):
-            job, out = str(tmp_path / ("smoke%d_%s.npz" % (seed, dt))), str(tmp_path / ("smoke%d_%s.npy" % (seed, dt)))
-            oc.write_job(job, opt.__dict__, sino, draws, wseed, 70, dtype=dt, nets="smoke")
-            lst.append((job, out))
-    outs = oc.run_jobs(jobs32 + jobs64, threads=12)
-    c32s, f64s = outs[:len(hips)], outs[len(hips):]
+    st = _once(oracle_pool, "arbiter_seeds", _arbiter_seeds_submit)
+    hips = st["hips"]
+    c32s, f64s = [oracle_pool.result(h) for h in st["h32"]], [oracle_pool.result(h) for h in st["h64"]]
     for h, c in zip(hips, c32s):
         print("reduced pipeline: |hip - cpu32| max %.3e rms %.3e (scale %.3f)" % (np.abs(h - c).max(), np.sqrt(((h - c).astype(np.float64) ** 2).mean()), np.abs(c).max()))
     _arbiter_ratios("reduced pipeline", hips, c32s, f64s)
@@ -1738,9 +1758,10 @@ def test_unet_true_size_vs_oracle(which):
     assert err <= 5e-5 * max(1.0, want.abs().max().item()), err
 
 
-def _full_size_run(opt_over, seed, phantoms, tmp_path, tag, arbiter=False):
+def _full_size_run(pool, opt_over, seed, phantoms, tag, replay=None, arbiter=False, threads=8):
     """The production networks at full size on the device (batch = len(phantoms), global slice ids 0..), the draws recorded,
-    then every slice replayed by the CPU oracle in its own child process (tests/_oracle_child.py), side by side."""
+    then the slices in `replay` (default: all) handed to the oracle pool: one float32 replay each in its own pinned child
+    process (tests/_oracle_child.py), with arbiter=True a float64 one too.  Returns (device output, [f32 handles], [f64 handles])."""
     from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
     from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, _RecordingNoise
     from ipdm_pytorch_amd.diffusion import NoiseSource
@@ -1754,19 +1775,19 @@ def _full_size_run(opt_over, seed, phantoms, tmp_path, tag, arbiter=False):
     rec = _RecordingNoise(NoiseSource(seed, 0))
     den.noise = rec
     got = den.progressive_denoiser(sharpen_num=70).cpu().numpy()
-    draws = [z.cpu().numpy() for z in rec.draws]
+    h32, h64 = [], []
+    for b in (range(len(phantoms)) if replay is None else replay):
+        draws = [z[b:b + 1].cpu().numpy() for z in rec.draws]
+        if arbiter:      # the same slice once more in float64: the value both float32 evaluations approximate (slowest: first)
+            job = pool.path("%s_job%d_f64.npz" % (tag, b))
+            oc.write_job(job, opt.__dict__, sinos[b], draws, 0, 70, dtype="float64")
+            h64.append(pool.submit("%s slice %d f64" % (tag, b), job, threads + 4))
+        job = pool.path("%s_job%d.npz" % (tag, b))
+        oc.write_job(job, opt.__dict__, sinos[b], draws, 0, 70)
+        h32.append(pool.submit("%s slice %d f32" % (tag, b), job, threads))
     del den, rec
     torch.cuda.empty_cache()
-    jobs, jobs64 = [], []
-    for b in range(len(phantoms)):
-        job, out = str(tmp_path / ("%s_job%d.npz" % (tag, b))), str(tmp_path / ("%s_out%d.npy" % (tag, b)))
-        oc.write_job(job, opt.__dict__, sinos[b], [d[b:b + 1] for d in draws], 0, 70)
-        jobs.append((job, out))
-        if arbiter:      # the same slice once more in float64: the value both float32 evaluations approximate
-            job, out = str(tmp_path / ("%s_job%d_f64.npz" % (tag, b))), str(tmp_path / ("%s_out%d_f64.npy" % (tag, b)))
-            oc.write_job(job, opt.__dict__, sinos[b], [d[b:b + 1] for d in draws], 0, 70, dtype="float64")
-            jobs64.append((job, out))
-    return (got, jobs, jobs64) if arbiter else (got, jobs)
+    return got, h32, h64
 
 
 def _check_full_size(got, want, phantom, max_rel):
@@ -1822,47 +1843,90 @@ def _arbiter_ratios(tag, hips, c32s, f64s):
     assert max(r_rms) <= ARBITER_WORST_RMS and max(r_max) <= ARBITER_WORST_MAX, msg
 
 
-def test_full_size_pipeline_psnr(tmp_path):
+HEADLINE_OVER = dict(t_start_proj=[15, 15, 15], t_start_img=[15], ultra_img_denoise=True)
+
+
+def _headline_submit(pool):
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser
+    got, h32, _ = _full_size_run(pool, HEADLINE_OVER, 1234, [0, 1], "headline", replay=[1], threads=32)
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    cfg_load(dict(HEADLINE_OVER, device=DEV), opt.__dict__)
+    one = progressive_domain_denoiser(opt, seed=1234)
+    sino0 = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(0)), seed=0)
+    one.data_sample_load(ldproj=torch.from_numpy(sino0)[None, None])
+    alone = one.progressive_denoiser(sharpen_num=70).cpu().numpy()
+    del one
+    torch.cuda.empty_cache()
+    return dict(got=got, h=h32[0], alone=alone)
+
+
+FULL_SIZE_SEEDS = (17, 23, 31, 47, 59)
+
+
+def _full_size_submit(pool):
+    runs = []
+    for k, seed in enumerate(FULL_SIZE_SEEDS):
+        got, h32, h64 = _full_size_run(pool, dict(t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=False), seed, [4 + k],
+                                       "s%d" % seed, arbiter=True, threads=8)
+        runs.append((got, h32[0], h64[0], 4 + k))
+    return runs
+
+
+# ---- device halves, in the order the pool should start their replays: the longest first
+@pytest.mark.oracle_submit
+def test_headline_configuration_device_run(oracle_pool):
+    """Device half of test_headline_configuration_full_length: B = 2 at the benched length + slice 0 alone; slice 1's replay
+    (75 network evaluations on 32 cores, ~5 min) starts here, at the head of the session."""
+    st = _once(oracle_pool, "headline", _headline_submit)
+    assert st["got"].shape == (2, 1, 512, 512) and np.isfinite(st["got"]).all()
+    assert np.array_equal(st["alone"], st["got"][0:1]), float(np.abs(st["alone"] - st["got"][0:1]).max())     # a batch is its slices
+
+
+@pytest.mark.oracle_submit
+def test_full_size_pipeline_device_run(oracle_pool):
+    """Device half of test_full_size_pipeline_psnr (five seeds, float32 + float64 replays submitted)."""
+    runs = _once(oracle_pool, "full_size", _full_size_submit)
+    assert len(runs) == len(FULL_SIZE_SEEDS) and all(np.isfinite(r[0]).all() for r in runs)
+
+
+@pytest.mark.oracle_submit
+def test_smoke_pipeline_device_runs(oracle_pool):
+    """Device halves of the three reduced-pipeline tests (stage-by-stage arbiter, arbiter over seven seeds, PSNR)."""
+    assert len(_once(oracle_pool, "arbiter_stages", _arbiter_stages_submit)) == len(ARBITER_STAGE_SEEDS)
+    assert len(_once(oracle_pool, "arbiter_seeds", _arbiter_seeds_submit)["hips"]) == 7
+    assert _once(oracle_pool, "smoke_psnr", _smoke_psnr_submit)["got"].shape == (1, 1, 512, 512)
+
+
+@pytest.mark.oracle_join
+def test_full_size_pipeline_psnr(oracle_pool):
     """End to end at full size with the production architectures, few steps, FIVE seeds (weights fixed; phantom, dose
     noise and diffusion draws vary): proj loop with adaptive guidance -> FBP -> sharpen -> img loop -- against the float32
     CPU oracle (north_star's PSNR criterion, max-abs 1e-4), and, with every slice replayed once more in FLOAT64, the fp64
     arbiter on the PRODUCTION kernels (conv_wino2 / conv_wino / conv_ws / conv_direct / attention_ws / the parity form):
     median over the seeds of err(HIP, fp64) / err(oracle32, fp64) <= 1.25 in rms and <= 1.5 in max-abs."""
-    from tests import _oracle_child as oc
-    runs = []
-    for k, seed in enumerate((17, 23, 31, 47, 59)):
-        got, jobs, jobs64 = _full_size_run(dict(t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=False), seed, [4 + k], tmp_path,
-                                           "s%d" % seed, arbiter=True)
-        runs.append((got, jobs[0], jobs64[0], 4 + k))
-    outs = oc.run_jobs([j for _, j, _, _ in runs] + [j for _, _, j, _ in runs], threads=12)
-    wants, f64s = outs[:len(runs)], outs[len(runs):]
+    runs = _once(oracle_pool, "full_size", _full_size_submit)
+    wants, f64s = [oracle_pool.result(r[1]) for r in runs], [oracle_pool.result(r[2]) for r in runs]
     report = [_check_full_size(got, want, ph, FULL_SIZE_MAX_REL) for (got, _, _, ph), want in zip(runs, wants)]
     print("full-size 5 seeds: max-abs %s rms %s" % (["%.2e" % r[0] for r in report], ["%.2e" % r[1] for r in report]))
     _arbiter_ratios("full size", [r[0] for r in runs], wants, f64s)
 
 
-def test_headline_configuration_full_length(tmp_path):
+@pytest.mark.oracle_join
+def test_headline_configuration_full_length(oracle_pool):
     """The BENCHED configuration at its real length (Utils/train_test_utils.py:552-567, Model/model.py:517-642):
     production UNets, 2000x912 sinograms, t_start_proj=[15,15,15] (adaptive guidance), FBP, sharpen, t_start_img=[15],
     ultra pass = 45 proj + 30 img network evaluations per slice, as a batch of TWO slices (global ids 0, 1) on the device.
     Slice 1 -- the one whose batch index, noise key and statistics rows are not those of a batch of one -- is replayed by
-    the CPU oracle with the recorded draws (a pinned child process, ~5 min of CPU; replaying both took 10 of the suite's 20
-    minutes); slice 0 must equal the same slice sampled alone on the device, bit for bit (a batch is its slices), and B = 1
-    runs are what test_full_size_pipeline_psnr holds against the oracle."""
-    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
-    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser
-    from tests import _oracle_child as oc
-    over = dict(t_start_proj=[15, 15, 15], t_start_img=[15], ultra_img_denoise=True)
-    got, jobs = _full_size_run(over, 1234, [0, 1], tmp_path, "headline")
-    want = oc.run_jobs(jobs[1:], threads=32)[0]
+    the CPU oracle with the recorded draws (a pinned child process, ~5 min of CPU, started by the device half at the head of
+    the session); slice 0 must equal the same slice sampled alone on the device, bit for bit (a batch is its slices), and
+    B = 1 runs are what test_full_size_pipeline_psnr holds against the oracle.  (All eight slices of the BENCHED batch against
+    the oracle: tools/b8_vs_oracle.py, profiles/r06_b8_vs_oracle.txt.)"""
+    st = _once(oracle_pool, "headline", _headline_submit)
+    got, alone = st["got"], st["alone"]
+    want = oracle_pool.result(st["h"], timeout=1100.0)
     rep = _check_full_size(got[1:2], want, 1, FULL_SIZE_MAX_REL)
-    opt = default_cfg([])
-    cfg_load(mayo_test_options(), opt.__dict__)
-    cfg_load(dict(over, device=DEV), opt.__dict__)
-    one = progressive_domain_denoiser(opt, seed=1234)
-    sino0 = synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(0)), seed=0)
-    one.data_sample_load(ldproj=torch.from_numpy(sino0)[None, None])
-    alone = one.progressive_denoiser(sharpen_num=70).cpu().numpy()
     assert np.array_equal(alone, got[0:1]), float(np.abs(alone - got[0:1]).max())
     msg = "headline full length B=2: slice 1 vs CPU oracle max-abs %.3e rms %.3e PSNR hip %.4f / cpu %.4f dB; slice 0 == the slice alone (bitwise)" % rep
     print(msg)

@@ -304,3 +304,34 @@ def test_img_denoiser_against_reference_harness(golden):
     for k, r in enumerate(res):
         np.testing.assert_allclose(r.numpy()[0, 0, ::16, ::16], g["img_iter_%d" % (k + 1)], rtol=0, atol=2e-6)
     np.testing.assert_allclose(res[-1].numpy()[0, 0, ::4, ::4], g["final_sub4"], rtol=0, atol=2e-6)
+
+
+def test_config_c1_against_reference_harness(golden):
+    """BASELINE.json config C1 at its literal setting (one 512x512 slice, image domain only, t_start_img=[5], constant
+    guidance 0.45, no ultra pass; Utils/train_test_utils.py:482-550) against the reference harness's own
+    img_denoiser(mode="img_only") (tests/golden/pipeline_c1.npz): every stored iterate, the result and its PSNR."""
+    from tests.golden.cases import PIPE_SEEDS, C1_OPT, C1_NOISE_SEED, C1_INPUT_SEED
+    g = golden("pipeline_c1")
+    opt = dict(_pipeline_opt().__dict__, **C1_OPT)
+    cfg_i = ou.UNetConfig(1, opt["model_channels_img"], 1, attention_resolutions=tuple(opt["attention_resolutions_img"]),
+                          channel_mult=tuple(opt["channel_mult_img"]), num_heads=4)
+    sd_i, _ = _sd(cfg_i, PIPE_SEEDS["img_weights"])
+    x = synth.rasterize(synth.ellipse_phantom(PIPE_SEEDS["phantom"])) + 0.004 * synth.hash_normal((512, 512), C1_INPUT_SEED)
+    x = torch.from_numpy(x.astype(np.float32))[None, None]
+    feed = noise_feed(C1_NOISE_SEED, (1, 1, 512, 512))
+    sch = od.Schedule(opt["timesteps_img"], opt["schedule_power_img"])
+    torch.set_num_threads(8)
+    res, _ = od.guided_reverse_process_slice(
+        sch, lambda xx, t: ou.unet_forward(cfg_i, sd_i, xx, t), x, t_start=opt["t_start_img"], eta=opt["eta_img"],
+        constant_guidance=opt["constant_guidance_img"], clip=opt["clip_img"], lambda_ratio=opt["lambda_ratio_img"], mode="img",
+        noise_fn=feed, ldct=x, kernel_size=opt["kernel_size_img"], amplitude=opt["amplitude_img"], noise_strength_in=None)
+    assert feed.count == int(g["ndraws"]) == 6
+    assert ["iter_%d" % (k + 1) for k in range(len(res))] == list(g["keys"])
+    for k, r in enumerate(res):
+        np.testing.assert_allclose(r.numpy()[0, 0, ::16, ::16], g["img_iter_%d" % (k + 1)], rtol=0, atol=2e-6)
+    out = res[-1].numpy()[0, 0]
+    np.testing.assert_allclose(out[::4, ::4], g["final_sub4"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out[254:258], g["final_rows"], rtol=0, atol=2e-6)
+    truth = od.miu2pixel(torch.from_numpy(synth.rasterize(synth.ellipse_phantom(PIPE_SEEDS["phantom"])))).numpy()
+    p = od.psnr(truth, od.miu2pixel(torch.from_numpy(out)).numpy())
+    assert abs(p - float(g["psnr_vs_phantom"])) <= 1e-4 * p
