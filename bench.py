@@ -90,8 +90,8 @@ def dominant_kernel(cls=5):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="slices per GPU (weak scaling: fixed per GPU)")
     ap.add_argument("--t_start_proj", type=int, nargs="+", default=[15, 15, 15])
     ap.add_argument("--t_start_img", type=int, nargs="+", default=[15])
@@ -111,22 +111,48 @@ def parse():
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child job and relay its line.  Nothing in this
-    process has touched the GPU (no torch import yet), and the job is a child process, not an exec of this one."""
+    process has touched the GPU (no torch import yet), and the job is a child process, not an exec of this one.  The port is
+    picked by binding and closing a socket; if somebody takes it in between, the rendezvous fails within seconds and the job
+    is started once more on a fresh port.  SIGTERM / SIGINT end the child job too (a driver's timeout must not leave ranks
+    behind)."""
+    import signal
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for ln in proc.stdout:                                  # rank 0's ONE JSON line to stdout, anything else to stderr
-        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln)
-        sys.stdout.flush()
-    return proc.wait()
+    rc = 1
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        t0 = time.time()
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+
+        def stop(signum, frame, proc=proc):
+            if hasattr(proc, "terminate"):
+                proc.terminate()
+            raise SystemExit(128 + signum)
+        old = {sg: signal.signal(sg, stop) for sg in (signal.SIGTERM, signal.SIGINT)}
+        relayed = False
+        try:
+            for ln in proc.stdout:                              # rank 0's ONE JSON line to stdout, anything else to stderr
+                relayed = relayed or ln.startswith("{")
+                (sys.stdout if ln.startswith("{") else sys.stderr).write(ln)
+                sys.stdout.flush()
+            rc = proc.wait()
+        finally:
+            for sg, h in old.items():
+                signal.signal(sg, h)
+            if hasattr(proc, "poll") and proc.poll() is None:  # (an exception in the relay: do not leave the ranks running)
+                proc.terminate()
+                proc.wait()
+        if rc == 0 or relayed or time.time() - t0 > 60:
+            break
+        sys.stderr.write("bench.py: the rank job ended with code %d after %.0f s without a result line; starting it again on a fresh port\n" % (rc, time.time() - t0))
+    return rc
 
 
 def make_inputs(batch, slice_id0, device, geometry=None):
@@ -237,14 +263,15 @@ def cpu_baseline_host(per_proc_threads, n_fwd_proj, n_fwd_img, budget_s=150.0):
         env = dict(os.environ, OMP_NUM_THREADS=str(per_proc_threads), MKL_NUM_THREADS=str(per_proc_threads), HIP_VISIBLE_DEVICES="",
                    CUDA_VISIBLE_DEVICES="")
         procs.append(subprocess.Popen([sys.executable, child, str(per_proc_threads), ",".join(map(str, mine)), str(budget_s)],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     res = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=budget_s * 3 + 120)
+            out, err = p.communicate(timeout=budget_s * 3 + 120)
             res.append(json.loads(out.strip().splitlines()[-1]))
-        except Exception:
+        except Exception as e:
             p.kill()
+            sys.stderr.write("bench.py: a host-baseline child failed (%s); value_host is dropped\n%s\n" % (e, (locals().get("err") or "")[-1500:]))
     if len(res) < P:
         return None
     img = sum(r["img"] for r in res) / len(res)
@@ -320,8 +347,30 @@ def main():
             out = local_step()
         return idist.all_gather_slices(out, n_global, rank, world)
 
-    for _ in range(args.warmup):
+    # Warm-up.  Under the LAST warm-up step (untimed) one extra wave samples the shader clock against the 100 MHz reference
+    # clock (ipdm_clock_probe, csrc/prof.hip) on a stream of its own: the clock this chip HOLDS under this workload -- what
+    # makes two boxes' (or a 1-step and a 20-step run's) lines comparable.  Nothing is co-resident with the timed region.
+    clock = None
+    t_w = None
+    for w in range(args.warmup):
+        probe = None
+        if rank == 0 and t_w is not None and w == args.warmup - 1 and not args.no_roofline:
+            period_us = 50000
+            n_s = max(4, min(400, int(0.8 * t_w * 1e6 / period_us)))
+            probe = (torch.zeros(2 * n_s, dtype=torch.int64, device=device), torch.cuda.Stream(device=device))
+            _lib.call("ipdm_clock_probe", C.c_void_p(probe[0].data_ptr()), n_s, period_us, C.c_void_p(probe[1].cuda_stream))
+        tw0 = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        t_w = time.perf_counter() - tw0
+        if probe is not None:
+            probe[1].synchronize()
+            tk = probe[0].cpu().numpy().reshape(-1, 2).astype("float64")
+            ghz = sorted(((tk[1:, 0] - tk[:-1, 0]) / (tk[1:, 1] - tk[:-1, 1]) * 0.1).tolist())
+            clock = {"ghz_median": round(ghz[len(ghz) // 2], 3), "ghz_min": round(ghz[0], 3), "ghz_max": round(ghz[-1], 3),
+                     "samples": len(ghz), "period_ms": period_us // 1000,
+                     "note": "shader clock held under the LAST warm-up step (one extra wave reading s_memtime against the 100 MHz "
+                             "s_memrealtime on its own stream; nothing co-resident with the timed region)"}
     torch.cuda.synchronize()
     idist.barrier()
     prof = (not args.no_roofline) and rank == 0
@@ -334,9 +383,12 @@ def main():
         _lib.call("ipdm_profile_begin_classes", 200000, sum(1 << c for c in DOM_CLASSES))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # one event per step boundary: no host sync
+    step_ev[0].record()
+    for i in range(args.steps):
         draw0 = den._noise().draw          # first draw index of the last timed step (alt-mode comparison below)
         out = step(timed=True)
+        step_ev[i + 1].record()
     draws_per_step = den._noise().draw - draw0
     torch.cuda.synchronize()
     idist.barrier()
@@ -345,6 +397,7 @@ def main():
     # per rank: the mean over the timed steps of its own work (event pairs around local_step(), the all-gather excluded)
     own_mean = (sum(a.elapsed_time(b) for a, b in own_ev) / len(own_ev)) if own_ev else elapsed / args.steps * 1e3
     own_ms = idist.gather_over_ranks(own_mean, device)
+    per_step = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
     elapsed = idist.max_over_ranks(elapsed, device)
     roofline = None
     extra = {}
@@ -415,7 +468,11 @@ def main():
         line = {
             "metric": "CT slices/s (full proj+img partial-diffusion sample)", "value": round(value, 5),
             "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "per_step_ms": {"first": round(per_step[0], 2), "median": round(sorted(per_step)[len(per_step) // 2], 2),
+                            "last": round(per_step[-1], 2), "min": round(min(per_step), 2), "max": round(max(per_step), 2),
+                            "note": "rank 0's timed steps one by one (HIP events at the step boundaries on the launch stream)"},
+            "clock": clock, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE config C3 shape: proj UNet x%d @1152x736 (views x detectors) + HIP FBP to 512x512, "
                                     "t_start_proj=%s (NOT the headline)" % (n_fwd_proj, args.t_start_proj)) if alt else

@@ -59,6 +59,13 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef IPDM_WINO2_DEFER
 #define IPDM_WINO2_DEFER 0          // 1: the eight 16-byte stores of an interior tile are issued under the NEXT tile's first MFMAs (round 5 experiment)
 #endif
+#ifndef IPDM_WINO2_SEL
+#define IPDM_WINO2_SEL 1            // 1 (round 6): which of the wave's two channels a staging slot belongs to is a CONSTANT lane mask (slot u = lane + 64 j,
+#endif                              //    channel u / 54: j = 1 always the second, j = 0 the second from lane 54 on; planar: 60) -- the select takes it as an
+                                    //    immediate SGPR pair instead of a compare result the compiler keeps alive (and spills) for the kernel's lifetime
+#ifndef IPDM_WINO2_BMASK
+#define IPDM_WINO2_BMASK 1          // 1 (round 6): the border tiles' per-element zeroing as v_bfe_i32 + v_and_b32 on the lane's bit mask instead of eight
+#endif                              //    v_cndmask on eight 64-bit SGPR masks recomputed per tile (sixteen SGPRs held through the chunk loop -> spills)
 #ifndef IPDM_CONV_STAMPS
 #define IPDM_CONV_STAMPS 0          // `make stamps`: in-kernel s_memtime stamps of the phases (a stamped build changes what it measures)
 #endif
@@ -284,7 +291,16 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         if (a.act) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (IPDM_WINO2_SGN && !(e & 1)) {      // (the slot's channel: the first or the second of the wave's two)
+                if (IPDM_WINO2_SGN && IPDM_WINO2_SEL && !(e & 1)) {
+                    if (e == 0) {      // slot j = 0: lanes 0..53 (planar x1: 0..59) hold the wave's first channel, the rest its second
+                        const unsigned long long m = (unsigned long long)((PLANAR && raw.planar) ? 0xf0000000u : 0xffc00000u) << 32;
+                        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(raw.sc[0]) : "v"(raw.ssc[0]), "v"(raw.ssc[1]), "s"(m));
+                        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(raw.sh[0]) : "v"(raw.ssh[0]), "v"(raw.ssh[1]), "s"(m));
+                    } else {           // slot j = 1: the second channel (the lanes without a slot park what they compute in their dump slot)
+                        raw.sc[1] = raw.ssc[1];
+                        raw.sh[1] = raw.ssh[1];
+                    }
+                } else if (IPDM_WINO2_SGN && !(e & 1)) {      // (the slot's channel: the first or the second of the wave's two)
                     const bool second = ((PLANAR && raw.planar) ? gnoffp[PLANAR ? (e >> 1) : 0] : gnoff[e >> 1]) != 0;
                     raw.sc[e >> 1] = second ? raw.ssc[1] : raw.ssc[0];
                     raw.sh[e >> 1] = second ? raw.ssh[1] : raw.ssh[0];
@@ -309,7 +325,15 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         if (a_bord) {
             const unsigned vm = pl ? a_vmp : a_vm;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d[e >> 1][e & 1] = (vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
+            for (int e = 0; e < 8; ++e) {
+                if (IPDM_WINO2_BMASK) {      // bit e of the lane's mask, sign-extended: 0 / ~0 (volatile: not to be hoisted into eight live registers)
+                    int keep;
+                    asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(vm), "n"(e));
+                    d[e >> 1][e & 1] = __builtin_bit_cast(float, __builtin_bit_cast(int, d[e >> 1][e & 1]) & keep);
+                } else {
+                    d[e >> 1][e & 1] = (vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
+                }
+            }
         }
         if (pl) {            // every other window column: the de-interleaved half of the scratch row
 #pragma unroll

@@ -41,3 +41,19 @@ def test_the_scanner_flags_the_shelved_pointwise_kernel(tmp_path):
     subprocess.run(cmd2, check=True, capture_output=True, timeout=900)
     r2 = subprocess.run([sys.executable, CHECK, cmd2[-1]], capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stdout[-2000:]
+
+
+def test_the_scanner_treats_both_operands_of_a_swap_as_written():
+    """v_permlane16_swap_b32 / v_swap_b32 write BOTH operands (conv_wup2 and conv_wino2 issue such swaps around their 16-byte
+    stores): a swap whose SECOND operand is a store's data register in the next slot is a hazard too; behind one wait state not."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_store_hazard as ch
+    assert ch.written("v_permlane16_swap_b32", ["v9", "v3"]) == [(9, 9), (3, 3)]
+    assert ch.written("v_add_co_u32", ["v1", "vcc", "v2", "v3"]) == [(1, 1)] and ch.written("v_cmp_lt_f32", ["vcc", "v1", "v2"]) == []
+    store = (0, "buffer_store_dwordx4", ["v[0:3]", "v8", "s[4:7]", "s9", "offen"])
+    swap = (8, "v_permlane16_swap_b32", ["v9", "v3"])
+    end = (24, "s_endpgm", [])
+    notes = []
+    assert len(ch.check({"k": [store, swap, end]}, "x.o", notes)) == 1
+    notes = []
+    assert ch.check({"k": [store, (8, "s_nop", ["0"]), (12, "v_permlane16_swap_b32", ["v9", "v3"]), end]}, "x.o", notes) == [] and len(notes) == 1

@@ -20,7 +20,23 @@ import subprocess
 import sys
 import tempfile
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def find_objdump():
+    """llvm-objdump of the toolchain that built the objects: $OBJDUMP, else next to $HIPCC's clang, else $ROCM_PATH, else /opt/rocm."""
+    cands = [os.environ.get("OBJDUMP")]
+    hipcc = shutil.which(os.environ.get("HIPCC", "hipcc"))
+    if hipcc:
+        root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+        cands += [os.path.join(root, "lib", "llvm", "bin", "llvm-objdump"), os.path.join(root, "llvm", "bin", "llvm-objdump")]
+    cands += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "llvm-objdump"), shutil.which("llvm-objdump")]
+    for c in cands:
+        if c and os.path.isfile(c) and os.access(c, os.X_OK):
+            return c
+    sys.exit("check_store_hazard: llvm-objdump not found (set OBJDUMP=/path/to/llvm-objdump; looked next to $HIPCC and under $ROCM_PATH)")
+
+
+OBJDUMP = find_objdump()
 STORE = re.compile(r"^(buffer|global|flat|scratch)_store_(dwordx3|dwordx4|b96|b128)\b")
 VREG = re.compile(r"^v(\d+)$|^v\[(\d+):(\d+)\]$")
 NEED = 1                       # issue slots the hardware needs between the store and the write
@@ -62,10 +78,17 @@ def parse(path):
 
 
 def written(mn, ops):
-    """VGPR range a VALU-class instruction writes (None: none / not a VALU instruction)."""
+    """VGPR ranges a VALU-class instruction writes ([]: none / not a VALU instruction).  v_swap_b32 and v_permlane16/32_swap_b32
+    write BOTH their operands; a VOP3 form whose first destination is an SGPR pair (v_add_co_u32 v1, vcc, ..: the VGPR comes first;
+    v_cmp / v_readlane: no VGPR destination at all) is covered by taking the first operands that parse as VGPRs."""
     if not mn.startswith("v_") or mn.startswith("v_cmp") and not mn.startswith("v_cmpx") or mn.startswith("v_readlane") or mn.startswith("v_readfirstlane"):
-        return None
-    return vrange(ops[0]) if ops else None
+        return []
+    if not ops:
+        return []
+    if "swap" in mn:
+        return [r for r in (vrange(o) for o in ops[:2]) if r]
+    r = vrange(ops[0])
+    return [r] if r else []
 
 
 def slots(mn, ops):
@@ -93,8 +116,8 @@ def check(funcs, where, notes):
                     continue
                 seen.add((j, used))
                 _, m2, o2 = ins[j]
-                w = written(m2, o2)
-                if w and not (w[1] < data[0] or w[0] > data[1]):
+                w = [r for r in written(m2, o2) if not (r[1] < data[0] or r[0] > data[1])]
+                if w:
                     (bad if used < NEED else notes).append("%s: %s: `%s %s` is followed after %d slot(s) by `%s %s`" % (
                         where, fn[:80], mn, ", ".join(ops), used, m2, ", ".join(o2)))
                     break
@@ -115,13 +138,16 @@ def check(funcs, where, notes):
 
 def main(paths):
     tmp = tempfile.mkdtemp(prefix="storehaz")
-    bad, notes, nobj, nstores = [], [], 0, 0
+    bad, notes, nobj, nstores, empty = [], [], 0, 0, []
     try:
         for p in paths:
             local = os.path.join(tmp, os.path.basename(p))
             shutil.copy(p, local)
-            subprocess.run([OBJDUMP, "--offloading", local], capture_output=True)
-            for co in sorted(glob.glob(local + ".*gfx950*")):
+            r = subprocess.run([OBJDUMP, "--offloading", local], capture_output=True, text=True)
+            cos = sorted(glob.glob(local + ".*gfx950*"))
+            if not cos:          # (host-only objects have none; reported only if NOTHING was found -- then the build is refused below)
+                empty.append("%s: `%s --offloading` extracted no gfx950 code object (rc %d) %s" % (p, OBJDUMP, r.returncode, r.stderr[-300:]))
+            for co in cos:
                 funcs = parse(co)
                 nobj += 1
                 nstores += sum(1 for ins in funcs.values() for (_, mn, _) in ins if STORE.match(mn))
@@ -130,6 +156,8 @@ def main(paths):
         shutil.rmtree(tmp, ignore_errors=True)
     for b in bad:
         print("STORE-DATA HAZARD  " + b)
+    if not nobj:
+        print("check_store_hazard: no device code found -- refusing\n  " + "\n  ".join(empty))
     print("check_store_hazard: %d code object(s), %d stores of more than 64 bits, %d hazard(s); %d write(s) one slot later (safe: noted)" % (
         nobj, nstores, len(bad), len(notes)))
     return 1 if bad or not nobj else 0
