@@ -184,6 +184,21 @@ def timed_leg(fn, warmup=1, steps=1):
     return (time.perf_counter() - t0) / steps, out
 
 
+def cpu_quota():
+    """CPUs of time this process's cgroup grants (cpu.max), or the logical CPU count without a quota.  The MI355X boxes of the
+    pool show 256 logical CPUs and grant SIXTEEN (cpu.max = "1600000 100000"): a baseline 'on the box's host cores' is a
+    baseline on those sixteen, whatever thread count it starts."""
+    n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            return max(1, min(n, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline():
     """The CPU oracle (a port: torch-CPU UNet restatement + C FBP) timed on this host's cores on a bounded
     sample -- img-UNet forwards @512x512 at a few thread counts (the best one is kept: torch-CPU convolutions
@@ -192,7 +207,7 @@ def cpu_baseline():
     import torch
     from oracle import unet as ou, fbp as of
     from ipdm_pytorch_amd import synth
-    cores = os.cpu_count() or 1
+    cores = cpu_quota()
     cfg_i = ou.UNetConfig()
     cfg_p = ou.UNetConfig(attention_resolutions=(16, 32), channel_mult=(1 / 16, 1 / 8, 1 / 4, 2, 2, 4, 4))
     sd_i = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_i), seed=1).items()}
@@ -203,7 +218,7 @@ def cpu_baseline():
     ou.unet_forward(cfg_i, sd_i, x_i[:, :, :128, :128], 7)        # warm-up: oneDNN primitive creation, allocator
     out = {"img": float("inf"), "proj": float("inf")}
     used = {"img": 1, "proj": 1}
-    for nt in sorted({min(cores, n) for n in (16, 32, 64, 128)}):
+    for nt in sorted({min(cores, n) for n in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
         ou.unet_forward(cfg_i, sd_i, x_i, 7)
@@ -223,7 +238,7 @@ def cpu_baseline():
     t0 = time.perf_counter()
     of.convert(geo, sino)
     out["fbp"] = time.perf_counter() - t0
-    return out, max(used.values()), cores
+    return out, max(used.values()), os.cpu_count() or 1
 
 
 def cpu_baseline_host(per_proc_threads, n_fwd_proj, n_fwd_img, budget_s=150.0):
@@ -237,7 +252,7 @@ def cpu_baseline_host(per_proc_threads, n_fwd_proj, n_fwd_img, budget_s=150.0):
                     if l and not l.startswith("#")})
     except Exception:
         phys = 0
-    phys = phys or (os.cpu_count() or 2) // 2
+    phys = min(phys or (os.cpu_count() or 2) // 2, cpu_quota())      # (a cgroup quota below the core count: that is the host we have)
     P = max(1, phys // per_proc_threads)
     # memory: a full-size oracle forward peaks below 32 GB (two of them run side by side in the 64 GB build container); never
     # start more processes than MemAvailable / 32 GB (a host driven out of memory takes the GPU box down with it)
@@ -601,14 +616,18 @@ def main():
             tb, used, cores = cpu_baseline()
             per_slice = n_fwd_proj * tb["proj"] + n_fwd_img * tb["img"] + tb["fbp"]
             line["cpu_baseline"] = {
-                "value": round(1.0 / per_slice, 6), "unit": "slices/s", "cores": used, "threads": used, "host_cores": cores,
+                "value": round(1.0 / per_slice, 6), "unit": "slices/s", "cores": min(used, cpu_quota()), "threads": used, "host_cores": cores,
+                "cpu_quota": cpu_quota(),
                 "cpu_model": cpu_model(), "torch": torch.__version__, "kind": "port",
-                "sample": "oracle (torch-CPU fp32 restatement + C FBP; best thread count per network out of 16/32/64/128 of the host's "
-                          "%d logical cores, %d at most) timed on 1 proj-UNet fwd @2000x912 (%.1fs), 1 img-UNet fwd @512x512 (%.1fs), "
+                "sample": "oracle (torch-CPU fp32 restatement + C FBP; best thread count per network out of 8/16/32/64/128 capped at the "
+                          "cgroup's CPU quota -- the host shows %d logical cores -- %d threads at most) timed on 1 proj-UNet fwd @2000x912 (%.1fs), 1 img-UNet fwd @512x512 (%.1fs), "
                           "1 FBP (%.1fs); extrapolated by call counts %d/%d/1 per slice" % (cores, used, tb["proj"], tb["img"], tb["fbp"], n_fwd_proj, n_fwd_img)}
             line["speedup_vs_cpu_baseline"] = round(value * per_slice, 1)
             # the host-filling figure beside it: P independent oracle processes on disjoint core sets, all running at once
             hb = cpu_baseline_host(16, n_fwd_proj, n_fwd_img)
+            if not hb:
+                line["cpu_baseline"]["host"] = {"note": "no host-filling figure: the cgroup grants %d CPUs of time (cpu.max), which one %d-thread "
+                                                        "oracle process already uses" % (cpu_quota(), used)}
             if hb:
                 # (a child that had no budget left for the proj forward: scale the single-process one by the img slow-down)
                 proj_t = hb["proj"] if hb["proj"] else tb["proj"] * hb["img"] / tb["img"]

@@ -32,6 +32,7 @@ extern "C" {
 
 const char *ipdm_last_error(void);
 /* ABI version of this header (bumped on any signature change or new entry point): 5. */
+#define IPDM_ABI_VERSION 5
 int ipdm_abi_version(void);
 
 /* Process-wide switches of the library (A/B experiments, opt-in evaluation modes); no reference counterpart -- the
@@ -41,7 +42,7 @@ int ipdm_abi_version(void);
  * README.md lists them.  Every switch starts from the environment variable IPDM_<NAME> (read once, kept
  * as a debug alias) and changes only through this call afterwards.  Switches that shape packed weights or kernel choice
  * are recorded by ipdm_unet_create: a forward on a handle created under other values fails with IPDM_ERR_INVALID instead
- * of running on a mismatched layout; per-call switches (conv_no_up2, conv_no_wino, conv_no_pw, pw_item, pw_force, wino_v1, wino2_min_tiles, conv1x1_no_quarter, conv_nm, direct_no_skip_fuse, gn_unfused,
+ * of running on a mismatched layout; per-call switches (conv_no_up2, conv_no_wup2, conv_no_wino, conv_no_pw, pw_item, pw_force, wino_v1, wino2_min_tiles, conv1x1_no_quarter, conv_nm, direct_no_skip_fuse, gn_unfused,
  * gn_two_stage, unet_transpose, attn_no_zseq, conv_dbg, art_per_view: every weight form they choose between is packed, the workspace
  * need is re-queried per forward) may change under a live handle.  Returns IPDM_ERR_INVALID for an unknown name. */
 int ipdm_set_option(const char *name, int value);

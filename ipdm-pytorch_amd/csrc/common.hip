@@ -133,7 +133,7 @@ int device_cu_count()
 }  // namespace ipdm
 
 extern "C" const char *ipdm_last_error(void) { return ipdm::g_err; }
-extern "C" int ipdm_abi_version(void) { return 5; }      // 2: ipdm_profile_end takes its array length; ipdm_conv_kernel_code  3: ipdm_profile_begin_classes  4: profile class 6 (IPDM_PROF_CLASSES 7); the split-bf16 switches are gone  5: profile class 7 (conv_wup2; IPDM_PROF_CLASSES 8), kernel code 11, option conv_no_wup2
+extern "C" int ipdm_abi_version(void) { return IPDM_ABI_VERSION; }      // 2: ipdm_profile_end takes its array length; ipdm_conv_kernel_code  3: ipdm_profile_begin_classes  4: profile class 6 (IPDM_PROF_CLASSES 7); the split-bf16 switches are gone  5: profile class 7 (conv_wup2; IPDM_PROF_CLASSES 8), kernel code 11, option conv_no_wup2
 
 extern "C" int ipdm_set_option(const char *name, int value)
 {

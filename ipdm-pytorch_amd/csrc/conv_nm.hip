@@ -332,5 +332,8 @@ static int conv2d_nm_launch_impl(const ConvArgs &a, hipStream_t st)
 // entry points of libipdm_hip_optin.so (csrc/optin.hip)
 // the copy of the product library this object's references resolved against (optin.hip compares it with its own)
 extern "C" const void *ipdm_optin_bound_to(void) { return (const void *)&ipdm_last_error; }
+// ... and the layout this object was COMPILED against: ABI version, sizeof(ConvArgs), number of option slots (a stale copy of
+// this library next to a newer product would otherwise misread ConvArgs and the option table silently)
+extern "C" void ipdm_optin_layout(int *out3) { out3[0] = IPDM_ABI_VERSION; out3[1] = (int)sizeof(ipdm::ConvArgs); out3[2] = (int)ipdm::OPT_COUNT; }
 extern "C" int ipdm_optin_conv_nm_eligible(const ipdm::ConvArgs *a) { return ipdm::conv_nm_eligible_impl(*a) ? 1 : 0; }
 extern "C" int ipdm_optin_conv2d_nm_launch(const ipdm::ConvArgs *a, hipStream_t st) { return ipdm::conv2d_nm_launch_impl(*a, st); }

@@ -44,6 +44,18 @@ void *optin_sym(const char *name)
                                "libipdm_hip.so to use the opt-in kernels)";
                 dlclose(g_handle);
                 g_handle = nullptr;
+            } else {
+                using Lay = void (*)(int *);
+                Lay lay = (Lay)dlsym(g_handle, "ipdm_optin_layout");
+                int got[3] = {-1, -1, -1};
+                if (lay) lay(got);
+                if (got[0] != IPDM_ABI_VERSION || got[1] != (int)sizeof(ConvArgs) || got[2] != (int)OPT_COUNT) {
+                    g_why = path + " was built against another layout (ABI " + std::to_string(got[0]) + ", ConvArgs " + std::to_string(got[1]) +
+                            " bytes, " + std::to_string(got[2]) + " options; this library: ABI " + std::to_string(IPDM_ABI_VERSION) + ", " +
+                            std::to_string(sizeof(ConvArgs)) + " bytes, " + std::to_string((int)OPT_COUNT) + "): rebuild both (make -C csrc)";
+                    dlclose(g_handle);
+                    g_handle = nullptr;
+                }
             }
         }
     }

@@ -6,10 +6,13 @@ records the draws and SUBMITS one tests/_oracle_child.py job per slice / seed / 
 the replays run side by side on the host cores -- round 5's suite serialised ~25 independent CPU jobs behind an idle GPU and
 did not fit the driver's 1200 s window.
 
-Cores: the physical cores (first half of the affinity list; the SMT siblings are the second half on the GPU boxes) minus a
-block reserved for the pytest process itself (in-process oracle comparisons, kernel launches); every job gets its own
-disjoint block (unpinned, five 32-thread torch processes ran 7x slower than one alone).  Jobs start in submission order as
-blocks free up (first fit), so the longest replay is submitted first.
+Cores.  The GPU boxes show 256 logical CPUs but their cgroup grants SIXTEEN CPUs of time (/sys/fs/cgroup/cpu.max = "1600000
+100000", measured round 6: profiles/r06a_box.txt): a hundred runnable threads are throttled to sixteen cores' worth, every job
+-- and the pytest process that launches the kernels -- stretches 3-6x, and round 6's first run of this pool (32 jobs, 104
+threads) took the headline replay from 300 s to 900 s.  The pool therefore sizes itself by the quota: capacity = quota - 2
+threads (the pytest process keeps two), every job pinned to its own physical cores (first half of the affinity list; the SMT
+siblings are the second half); jobs start in submission order as threads free up (first fit), so the longest replay is
+submitted first.  What fits that budget is the default suite; the full arbiter statistics run with IPDM_PARITY_FULL=1.
 """
 import os
 import subprocess
@@ -30,17 +33,42 @@ class Job:
         self.log = out + ".log"
 
 
+def cpu_quota():
+    """CPUs of time the cgroup grants (cpu.max / cfs quota), or the affinity count when there is no quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            return max(1, min(n, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            q, per = int(f.read()), int(g.read())
+        if q > 0:
+            return max(1, min(n, q // per))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def host_threads():
+    """Threads for CPU oracle work INSIDE the pytest process: a quarter of the CPU quota (the pool's replays hold the rest)."""
+    return max(2, min(32, cpu_quota() // 4))
+
+
 class OraclePool:
-    def __init__(self, reserve_main=24, pin_main=True):
+    def __init__(self, reserve_main=2):
         cpus = sorted(os.sched_getaffinity(0))
         phys = cpus[:len(cpus) // 2] if len(cpus) >= 16 else list(cpus)
-        if len(phys) >= 4 * reserve_main:
-            self.main_cores, self.free = phys[-reserve_main:], phys[:-reserve_main]
-            if pin_main:
-                try:        # the SMT siblings of the reserved block stay with the main process too
-                    os.sched_setaffinity(0, set(self.main_cores) | {c + len(cpus) // 2 for c in self.main_cores if c + len(cpus) // 2 in cpus})
-                except OSError:
-                    pass
+        self.quota = cpu_quota()
+        budget = min(self.quota, len(phys))
+        if budget >= 8:
+            # one core in every `stride`: the budgeted threads spread over the sockets' core complexes (their L3s and boost headroom)
+            stride = max(1, len(phys) // budget)
+            spread = phys[::stride][:budget]
+            self.main_cores, self.free = spread[-reserve_main:], spread[:budget - reserve_main]
             self.shared = False
         else:               # a small host (the CPU container): no reservation, at most two jobs at a time share what there is
             self.main_cores, self.free, self.shared = list(phys), list(phys), True
@@ -56,7 +84,7 @@ class OraclePool:
     # ------------------------------------------------------------------ public
     def main_threads(self):
         """Thread count for oracle work done inside the pytest process."""
-        return max(1, len(self.main_cores))
+        return host_threads()
 
     def path(self, name):
         return os.path.join(self.tmpdir, name)
@@ -84,7 +112,8 @@ class OraclePool:
         return (out, np.load(j.out + ".mid.npz")) if mid else out
 
     def report(self):
-        lines = ["oracle pool: %d jobs on %d cores (main process keeps %d); seconds since session start" % (len(self.jobs), self.capacity, len(self.main_cores))]
+        lines = ["oracle pool: %d jobs on %d threads (cgroup quota %d CPUs of %d visible; the pytest process keeps %d); seconds since session start" % (
+            len(self.jobs), self.capacity, self.quota, len(os.sched_getaffinity(0)), len(self.main_cores))]
         for j in self.jobs:
             lines.append("%-28s threads %2d submit %6.1f start %6.1f end %6.1f run %6.1f rc %s" % (
                 j.tag, j.threads, j.t_submit - self.t0, (j.t_start or 0) - self.t0, (j.t_end or 0) - self.t0,

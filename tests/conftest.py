@@ -29,6 +29,16 @@ def pytest_collection_modifyitems(session, config, items):
     items.sort(key=key)          # stable: the order inside a file is kept
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _host_threads():
+    """On a GPU box the pytest process shares the cgroup's CPU quota (16 CPUs on the MI355X pool) with the oracle pool's
+    replays: in-process torch-CPU work keeps to a quarter of it."""
+    import torch
+    if torch.cuda.is_available():
+        from tests._oracle_pool import host_threads
+        torch.set_num_threads(host_threads())
+
+
 @pytest.fixture(scope="session")
 def oracle_pool():
     """The session's pool of CPU oracle replays (tests/_oracle_pool.py).  The pytest process keeps a reserved block of cores."""

@@ -13,6 +13,7 @@ from oracle import diffusion as od   # noqa: E402
 from oracle import fbp as of         # noqa: E402
 from oracle import unet as ou        # noqa: E402
 from ipdm_pytorch_amd import synth   # noqa: E402
+from tests._oracle_pool import host_threads   # noqa: E402
 from tests.golden.cases import SMALL_CFGS, SMALL_SHAPES, LOOP_CFG, LOOP_CASES, noise_feed  # noqa: E402
 
 DEV = "cuda:0"
@@ -1413,21 +1414,51 @@ def _once(pool, tag, fn):
     return pool.stash[tag]
 
 
-def _smoke_psnr_submit(pool):
-    from ipdm_pytorch_amd.denoiser import smoke_pipeline
+# What the default suite replays is sized by the GPU boxes' CPU quota -- SIXTEEN CPUs of time (cpu.max), not the 256 logical CPUs
+# they show (tests/_oracle_pool.py): the headline-length replay alone is ~300 s of those sixteen.  Default: the headline slice,
+# three full-size seeds in float32 (one of them in float64 too), three reduced seeds in float32 + float64 with every stage kept.
+# IPDM_PARITY_FULL=1: the round-5 statistics -- five full-size seeds and seven reduced ones, each in float32 AND float64 -- same
+# tests, same code, ~25 min on such a box (profiles/r06_parity_full.log holds this round's run).
+PARITY_FULL = os.environ.get("IPDM_PARITY_FULL") == "1"
+
+# (noise seed, weight seed of the proj net [img: + 1], phantom); the first one is ipdm_pytorch_amd.denoiser.smoke_pipeline's
+REDUCED_SEEDS = ((11, 21, 1), (29, 102, 2), (43, 104, 3), (61, 106, 4), (83, 108, 5), (97, 110, 6), (113, 112, 7))[:7 if PARITY_FULL else 3]
+N_STAGE_SEEDS = 3        # ... of which the first three keep every stored iterate (stage-by-stage arbiter)
+
+
+def _reduced_submit(pool):
+    """The reduced pipeline (true geometry, 16-channel networks; 2+2 proj steps, FBP, sharpen, 2 img steps, ultra pass) for every
+    seed of REDUCED_SEEDS on the device, each replayed by the CPU oracle in float32 and float64; ONE set of replays serves the three
+    reduced-pipeline tests (PSNR of the canonical seed, stage-by-stage arbiter, arbiter over the seeds)."""
     from tests import _oracle_child as oc
-    got, inputs = smoke_pipeline(DEV)
-    job = pool.path("smoke_psnr.npz")
-    oc.write_job(job, inputs["opt"], inputs["ldproj"], [z.numpy() for z in inputs["noise"]], 21, 70, nets="smoke")
-    return dict(got=got, h=pool.submit("smoke pipeline f32", job, 8))
+    runs = []
+    for k, (seed, wp, ph) in enumerate(REDUCED_SEEDS):
+        stages = k < N_STAGE_SEEDS
+        den, opt, sino = _reduced_denoiser(seed, wp, wp + 1, ph, save_it_state_proj=stages, save_it_state_img=stages)
+        out = den.progressive_denoiser(save_proj_state=stages, sharpen_num=70).cpu().numpy()
+        draws = [z.cpu().numpy() for z in den.noise.draws]
+        hs = {}
+        for dt, thr in (("float64", 3), ("float32", 2)):
+            job = pool.path("reduced%d_%s.npz" % (seed, dt))
+            oc.write_job(job, opt.__dict__, sino, draws, wp, 70, dtype=dt, nets="smoke", mid=stages)
+            hs[dt] = pool.submit("reduced seed %d %s" % (seed, dt), job, thr)
+        hip = None
+        if stages:
+            n_p = len(den.proj_denoise_result)
+            hip = ([np.array(den.proj_denoise_result[j + 1]) for j in range(n_p)], np.array(den.proj_denoise_convert2img_result[n_p]),
+                   [np.array(den.progressive_denoise_result[j + 1]) for j in range(len(den.progressive_denoise_result))])
+        runs.append(dict(seed=seed, out=out, hip=hip, h=hs))
+    return runs
 
 
 @pytest.mark.oracle_join
 def test_smoke_pipeline_matches_oracle_psnr(oracle_pool):
     """proj GRP -> FBP -> sharpen -> img GRP -> ultra on a real-geometry phantom sinogram, reduced UNets.
     north_star: PSNR (vs ground truth, on miu2pixel images) within 1e-4 relative of the CPU path."""
-    st = _once(oracle_pool, "smoke_psnr", _smoke_psnr_submit)
-    got, want = st["got"], oracle_pool.result(st["h"])
+    from ipdm_pytorch_amd.denoiser import smoke_pipeline
+    run = _once(oracle_pool, "reduced", _reduced_submit)[0]          # REDUCED_SEEDS[0] IS smoke_pipeline's configuration ...
+    got, want = run["out"], oracle_pool.result(run["h"]["float32"])
+    assert np.array_equal(smoke_pipeline(DEV)[0], got)              # ... bit for bit (what __graft_entry__.smoke() runs)
     assert got.shape == want.shape == (1, 1, 512, 512)
     # Eleven evaluations of random-weight networks amplify float32 rounding ~100x: the float32 CPU oracle itself ends
     # 2.4e-4 (max-abs; rms 3.7e-6) from the float64 value of the same function (test_smoke_pipeline_fp64_arbiter, which
@@ -1463,28 +1494,6 @@ def _reduced_denoiser(seed, wp, wi, phantom, **over):
     return den, opt, sino
 
 
-ARBITER_STAGE_SEEDS = ((11, 21, 1), (29, 102, 2), (43, 104, 3))        # (noise seed, weight seed of the proj net [img: +1], phantom)
-
-
-def _arbiter_stages_submit(pool):
-    from tests import _oracle_child as oc
-    runs = []
-    for seed, wp, ph in ARBITER_STAGE_SEEDS:
-        den, opt, sino = _reduced_denoiser(seed, wp, wp + 1, ph, save_it_state_proj=True, save_it_state_img=True)
-        den.progressive_denoiser(save_proj_state=True, sharpen_num=70)
-        draws = [z.cpu().numpy() for z in den.noise.draws]
-        hs = {}
-        for dt, thr in (("float64", 10), ("float32", 6)):
-            job = pool.path("stage%d_%s.npz" % (seed, dt))
-            oc.write_job(job, opt.__dict__, sino, draws, wp, 70, dtype=dt, nets="smoke", mid=True)
-            hs[dt] = pool.submit("stages seed %d %s" % (seed, dt), job, thr)
-        n_p = len(den.proj_denoise_result)
-        hip = ([np.array(den.proj_denoise_result[j + 1]) for j in range(n_p)], np.array(den.proj_denoise_convert2img_result[n_p]),
-               [np.array(den.progressive_denoise_result[j + 1]) for j in range(len(den.progressive_denoise_result))])
-        runs.append(dict(seed=seed, hip=hip, h=hs))
-    return runs
-
-
 @pytest.mark.oracle_join
 def test_smoke_pipeline_fp64_arbiter(oracle_pool):
     """Who is right when two float32 evaluations differ?  The reduced end-to-end pipeline once more on the CPU in FLOAT64
@@ -1500,7 +1509,7 @@ def test_smoke_pipeline_fp64_arbiter(oracle_pool):
         e = np.abs(np.asarray(a, dtype=np.float64).reshape(np.asarray(b).shape) - np.asarray(b, dtype=np.float64))
         return float(e.max()), float(np.sqrt((e ** 2).mean()))
     per_stage = {}                       # stage -> [(ratio max-abs, ratio rms, amplified)] over the seeds
-    for k, run in enumerate(_once(oracle_pool, "arbiter_stages", _arbiter_stages_submit)):
+    for k, run in enumerate(_once(oracle_pool, "reduced", _reduced_submit)[:N_STAGE_SEEDS]):
         seed, hip = run["seed"], run["hip"]
         (_, z64), (_, z32) = oracle_pool.result(run["h"]["float64"], mid=True), oracle_pool.result(run["h"]["float32"], mid=True)
         m64, m32 = (z64["proj"], z64["fbp"], z64["img"]), (z32["proj"], z32["fbp"], z32["img"])
@@ -1533,30 +1542,16 @@ def test_smoke_pipeline_fp64_arbiter(oracle_pool):
             assert med_rms <= ARBITER_MEDIAN_RMS and med_max <= ARBITER_MEDIAN_MAX, (name, rs)
 
 
-def _arbiter_seeds_submit(pool):
-    from tests import _oracle_child as oc
-    hips, h32, h64 = [], [], []
-    for k, seed in enumerate((11, 29, 43, 61, 83, 97, 113)):      # (round 5: two more -- a median of 1.32 under 1.5 on five was thin)
-        wseed = 100 + 2 * k
-        den, opt, sino = _reduced_denoiser(seed, wseed, wseed + 1, k + 1)
-        hips.append(den.progressive_denoiser(sharpen_num=70).cpu().numpy())
-        draws = [z.cpu().numpy() for z in den.noise.draws]
-        for dt, lst, thr in (("float64", h64, 6), ("float32", h32, 4)):
-            job = pool.path("smoke%d_%s.npz" % (seed, dt))
-            oc.write_job(job, opt.__dict__, sino, draws, wseed, 70, dtype=dt, nets="smoke")
-            lst.append(pool.submit("reduced seed %d %s" % (seed, dt), job, thr))
-    return dict(hips=hips, h32=h32, h64=h64)
-
-
 @pytest.mark.oracle_join
 def test_smoke_pipeline_fp64_arbiter_over_seeds(oracle_pool):
     """The fp64 arbiter as a statistic: the reduced end-to-end pipeline (proj loop 2+2 steps, FBP, sharpen, img loop, ultra
-    pass) for SEVEN seeds -- network weights, phantom, dose noise and diffusion draws all vary -- each replayed by the CPU
-    oracle in float32 and in float64 (pinned child processes).  Median over the seeds of err(HIP, fp64) / err(oracle32,
-    fp64) at the END of the chain (after the amplifying image-domain passes): <= 1.25 in rms, <= 1.5 in max-abs."""
-    st = _once(oracle_pool, "arbiter_seeds", _arbiter_seeds_submit)
-    hips = st["hips"]
-    c32s, f64s = [oracle_pool.result(h) for h in st["h32"]], [oracle_pool.result(h) for h in st["h64"]]
+    pass) over the seeds of REDUCED_SEEDS (three by default, SEVEN under IPDM_PARITY_FULL=1) -- network weights, phantom, dose
+    noise and diffusion draws all vary -- each replayed by the CPU oracle in float32 and in float64 (pinned child processes).
+    Median over the seeds of err(HIP, fp64) / err(oracle32, fp64) at the END of the chain (after the amplifying image-domain
+    passes): <= 1.25 in rms, <= 1.5 in max-abs."""
+    runs = _once(oracle_pool, "reduced", _reduced_submit)
+    hips = [r["out"] for r in runs]
+    c32s, f64s = [oracle_pool.result(r["h"]["float32"]) for r in runs], [oracle_pool.result(r["h"]["float64"]) for r in runs]
     for h, c in zip(hips, c32s):
         print("reduced pipeline: |hip - cpu32| max %.3e rms %.3e (scale %.3f)" % (np.abs(h - c).max(), np.sqrt(((h - c).astype(np.float64) ** 2).mean()), np.abs(c).max()))
     _arbiter_ratios("reduced pipeline", hips, c32s, f64s)
@@ -1752,13 +1747,13 @@ def test_unet_true_size_vs_oracle(which):
     net, sd = _native_unet(kw, 6)
     x = torch.from_numpy(synth.hash_normal(shape, 401))
     got = net(x.to(DEV), 13).cpu()
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    torch.set_num_threads(host_threads())      # (a quarter of the box's CPU quota: the oracle pool's replays hold the rest)
     want = ou.unet_forward(ou.UNetConfig(**kw), sd, x, 13)
     err = (got - want).abs().max().item()
     assert err <= 5e-5 * max(1.0, want.abs().max().item()), err
 
 
-def _full_size_run(pool, opt_over, seed, phantoms, tag, replay=None, arbiter=False, threads=8):
+def _full_size_run(pool, opt_over, seed, phantoms, tag, replay=None, arbiter=False, threads=3):
     """The production networks at full size on the device (batch = len(phantoms), global slice ids 0..), the draws recorded,
     then the slices in `replay` (default: all) handed to the oracle pool: one float32 replay each in its own pinned child
     process (tests/_oracle_child.py), with arbiter=True a float64 one too.  Returns (device output, [f32 handles], [f64 handles])."""
@@ -1781,7 +1776,7 @@ def _full_size_run(pool, opt_over, seed, phantoms, tag, replay=None, arbiter=Fal
         if arbiter:      # the same slice once more in float64: the value both float32 evaluations approximate (slowest: first)
             job = pool.path("%s_job%d_f64.npz" % (tag, b))
             oc.write_job(job, opt.__dict__, sinos[b], draws, 0, 70, dtype="float64")
-            h64.append(pool.submit("%s slice %d f64" % (tag, b), job, threads + 4))
+            h64.append(pool.submit("%s slice %d f64" % (tag, b), job, threads + 1))
         job = pool.path("%s_job%d.npz" % (tag, b))
         oc.write_job(job, opt.__dict__, sinos[b], draws, 0, 70)
         h32.append(pool.submit("%s slice %d f32" % (tag, b), job, threads))
@@ -1839,7 +1834,8 @@ def _arbiter_ratios(tag, hips, c32s, f64s):
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "arbiter_%s.txt" % tag.replace(" ", "_")), "w") as f:
         f.write(msg + "\n" + "rms ratios %s\nmax-abs ratios %s\n" % (["%.3f" % x for x in r_rms], ["%.3f" % x for x in r_max]))
-    assert np.median(r_rms) <= ARBITER_MEDIAN_RMS and np.median(r_max) <= ARBITER_MEDIAN_MAX, msg
+    if len(r_rms) >= 3:          # (a median of fewer is a single draw: the hard caps below are what holds then)
+        assert np.median(r_rms) <= ARBITER_MEDIAN_RMS and np.median(r_max) <= ARBITER_MEDIAN_MAX, msg
     assert max(r_rms) <= ARBITER_WORST_RMS and max(r_max) <= ARBITER_WORST_MAX, msg
 
 
@@ -1849,7 +1845,7 @@ HEADLINE_OVER = dict(t_start_proj=[15, 15, 15], t_start_img=[15], ultra_img_deno
 def _headline_submit(pool):
     from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
     from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser
-    got, h32, _ = _full_size_run(pool, HEADLINE_OVER, 1234, [0, 1], "headline", replay=[1], threads=32)
+    got, h32, _ = _full_size_run(pool, HEADLINE_OVER, 1234, [0, 1], "headline", replay=[1], threads=9)
     opt = default_cfg([])
     cfg_load(mayo_test_options(), opt.__dict__)
     cfg_load(dict(HEADLINE_OVER, device=DEV), opt.__dict__)
@@ -1862,15 +1858,16 @@ def _headline_submit(pool):
     return dict(got=got, h=h32[0], alone=alone)
 
 
-FULL_SIZE_SEEDS = (17, 23, 31, 47, 59)
+FULL_SIZE_SEEDS = (17, 23, 31, 47, 59)[:5 if PARITY_FULL else 3]
+FULL_SIZE_F64 = len(FULL_SIZE_SEEDS) if PARITY_FULL else 1      # how many of them are replayed in float64 too (the arbiter)
 
 
 def _full_size_submit(pool):
     runs = []
     for k, seed in enumerate(FULL_SIZE_SEEDS):
         got, h32, h64 = _full_size_run(pool, dict(t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=False), seed, [4 + k],
-                                       "s%d" % seed, arbiter=True, threads=8)
-        runs.append((got, h32[0], h64[0], 4 + k))
+                                       "s%d" % seed, arbiter=k < FULL_SIZE_F64)
+        runs.append((got, h32[0], h64[0] if h64 else None, 4 + k))
     return runs
 
 
@@ -1878,7 +1875,7 @@ def _full_size_submit(pool):
 @pytest.mark.oracle_submit
 def test_headline_configuration_device_run(oracle_pool):
     """Device half of test_headline_configuration_full_length: B = 2 at the benched length + slice 0 alone; slice 1's replay
-    (75 network evaluations on 32 cores, ~5 min) starts here, at the head of the session."""
+    (75 network evaluations on nine of the box's sixteen CPUs, ~7 min) starts here, at the head of the session."""
     st = _once(oracle_pool, "headline", _headline_submit)
     assert st["got"].shape == (2, 1, 512, 512) and np.isfinite(st["got"]).all()
     assert np.array_equal(st["alone"], st["got"][0:1]), float(np.abs(st["alone"] - st["got"][0:1]).max())     # a batch is its slices
@@ -1886,31 +1883,33 @@ def test_headline_configuration_device_run(oracle_pool):
 
 @pytest.mark.oracle_submit
 def test_full_size_pipeline_device_run(oracle_pool):
-    """Device half of test_full_size_pipeline_psnr (five seeds, float32 + float64 replays submitted)."""
+    """Device half of test_full_size_pipeline_psnr (FULL_SIZE_SEEDS; float32 replays, float64 ones for the first FULL_SIZE_F64)."""
     runs = _once(oracle_pool, "full_size", _full_size_submit)
     assert len(runs) == len(FULL_SIZE_SEEDS) and all(np.isfinite(r[0]).all() for r in runs)
 
 
 @pytest.mark.oracle_submit
 def test_smoke_pipeline_device_runs(oracle_pool):
-    """Device halves of the three reduced-pipeline tests (stage-by-stage arbiter, arbiter over seven seeds, PSNR)."""
-    assert len(_once(oracle_pool, "arbiter_stages", _arbiter_stages_submit)) == len(ARBITER_STAGE_SEEDS)
-    assert len(_once(oracle_pool, "arbiter_seeds", _arbiter_seeds_submit)["hips"]) == 7
-    assert _once(oracle_pool, "smoke_psnr", _smoke_psnr_submit)["got"].shape == (1, 1, 512, 512)
+    """Device half of the three reduced-pipeline tests (PSNR of the canonical seed, stage-by-stage arbiter, arbiter over the seeds)."""
+    runs = _once(oracle_pool, "reduced", _reduced_submit)
+    assert len(runs) == len(REDUCED_SEEDS) and all(r["out"].shape == (1, 1, 512, 512) and np.isfinite(r["out"]).all() for r in runs)
 
 
 @pytest.mark.oracle_join
 def test_full_size_pipeline_psnr(oracle_pool):
-    """End to end at full size with the production architectures, few steps, FIVE seeds (weights fixed; phantom, dose
-    noise and diffusion draws vary): proj loop with adaptive guidance -> FBP -> sharpen -> img loop -- against the float32
-    CPU oracle (north_star's PSNR criterion, max-abs 1e-4), and, with every slice replayed once more in FLOAT64, the fp64
-    arbiter on the PRODUCTION kernels (conv_wino2 / conv_wino / conv_ws / conv_direct / attention_ws / the parity form):
-    median over the seeds of err(HIP, fp64) / err(oracle32, fp64) <= 1.25 in rms and <= 1.5 in max-abs."""
+    """End to end at full size with the production architectures, few steps, over FULL_SIZE_SEEDS (three by default, FIVE
+    under IPDM_PARITY_FULL=1; weights fixed; phantom, dose noise and diffusion draws vary): proj loop with adaptive guidance ->
+    FBP -> sharpen -> img loop -- against the float32 CPU oracle (north_star's PSNR criterion, max-abs 1e-4), and, for the
+    first FULL_SIZE_F64 seeds (one by default, all under IPDM_PARITY_FULL=1) replayed once more in FLOAT64, the fp64 arbiter on
+    the PRODUCTION kernels (conv_wino2 / conv_wino / conv_ws / conv_direct / attention_ws / the parity form): err(HIP, fp64) /
+    err(oracle32, fp64) under the hard caps for every seed and, with three seeds or more, its median <= 1.25 in rms and <= 1.5
+    in max-abs (nothing amplifies at full size: round 4-5 measured 0.99 ... 1.03 rms, 0.93 ... 1.24 max-abs over five seeds)."""
     runs = _once(oracle_pool, "full_size", _full_size_submit)
-    wants, f64s = [oracle_pool.result(r[1]) for r in runs], [oracle_pool.result(r[2]) for r in runs]
+    wants = [oracle_pool.result(r[1]) for r in runs]
     report = [_check_full_size(got, want, ph, FULL_SIZE_MAX_REL) for (got, _, _, ph), want in zip(runs, wants)]
-    print("full-size 5 seeds: max-abs %s rms %s" % (["%.2e" % r[0] for r in report], ["%.2e" % r[1] for r in report]))
-    _arbiter_ratios("full size", [r[0] for r in runs], wants, f64s)
+    print("full-size %d seeds: max-abs %s rms %s" % (len(runs), ["%.2e" % r[0] for r in report], ["%.2e" % r[1] for r in report]))
+    arb = [(r[0], w, oracle_pool.result(r[2])) for r, w in zip(runs, wants) if r[2] is not None]
+    _arbiter_ratios("full size", [a[0] for a in arb], [a[1] for a in arb], [a[2] for a in arb])
 
 
 @pytest.mark.oracle_join
