@@ -2,7 +2,8 @@
 """Basic-block census of a kernel's gfx950 code: per block the MFMA, SGPR-spill lane moves (v_readlane / v_writelane), scratch,
 v_cndmask, vector-memory, LDS, other-VALU and SALU counts, with the branch edges -- what the spill gate of csrc/Makefile and
 NOTEBOOK.md's instruction counts are read from.
-    python tools/isa_census.py <file.o> <kernel-name-substring> [--blocks]"""
+    python tools/isa_census.py <file.o> <kernel-name-substring> [--blocks] [--gate N]
+--gate N: exit 1 if a block of >= 16 MFMAs of a matching kernel holds more than N lane moves or any scratch access (csrc/Makefile)."""
 import os
 import re
 import subprocess
@@ -64,6 +65,8 @@ def stats(bl):
 
 def main():
     obj, pat = sys.argv[1], sys.argv[2]
+    gate = int(sys.argv[sys.argv.index("--gate") + 1]) if "--gate" in sys.argv else None
+    bad, seen = [], 0
     for name, ins in disassemble(obj).items():
         if pat not in name:
             continue
@@ -72,6 +75,9 @@ def main():
         print("%s: %d instructions, %d blocks | v_readlane %d v_writelane %d scratch %d v_cndmask %d" % (
             name, tot["n"], len(bls), tot["rdlane"], tot["wrlane"], tot["scratch"], tot["cnd"]))
         mf = [stats(b) for b in bls if stats(b)["mfma"] >= 16]
+        seen += 1
+        bad += ["%s: a %d-MFMA block with %d lane moves, %d scratch accesses" % (name, s["mfma"], s["rdlane"] + s["wrlane"], s["scratch"])
+                for s in mf if gate is not None and (s["rdlane"] + s["wrlane"] > gate or s["scratch"])]
         print("   MFMA blocks: " + "; ".join("%d mfma + %d other valu (%d lane moves, %d scratch)" % (
             s["mfma"], s["valu"], s["rdlane"] + s["wrlane"], s["scratch"]) for s in mf))
         if "--blocks" in sys.argv:
@@ -81,6 +87,11 @@ def main():
                 print("   %06x n=%3d mfma=%2d rl=%2d wl=%2d scr=%2d cnd=%2d vmem=%2d lds=%2d valu=%3d salu=%3d -> %s%s" % (
                     b[0][0], s["n"], s["mfma"], s["rdlane"], s["wrlane"], s["scratch"], s["cnd"], s["vmem"], s["lds"], s["valu"], s["salu"],
                     x.split()[0] if "branch" in x else "fall", " %06x" % t if t else ""))
+
+
+    if gate is not None and (bad or not seen):
+        print("isa_census gate (%d lane moves per MFMA block, no scratch): REFUSED\n  " % gate + "\n  ".join(bad or ["no kernel matched " + pat]))
+        sys.exit(1)
 
 
 if __name__ == "__main__":
