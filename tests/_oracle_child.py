@@ -24,18 +24,20 @@ SMOKE_PROJ = dict(in_channels=1, model_channels=16, out_channels=1, attention_re
 SMOKE_IMG = dict(in_channels=1, model_channels=16, out_channels=1, attention_resolutions=(8,), channel_mult=(1, 1, 2, 2, 4), num_heads=1)
 
 
-def write_job(path, opt_dict, sino, draws, weight_seed, sharpen_num, dtype="float32", nets="full", mid=False):
+def write_job(path, opt_dict, sino, draws, weight_seed, sharpen_num, dtype="float32", nets="full", mid=False, img_only=False):
     """draws: the recorded [1,1,h,w] tensors/arrays of ONE slice, in order (sinogram-shaped ones first, then image-shaped).
     dtype "float64": the ARBITER run -- the same float32 inputs, weights and draws evaluated in double precision.
     nets "full": the production architectures, both with synthetic weights of seed `weight_seed`; "smoke": the reduced
     16-channel networks of ipdm_pytorch_amd.denoiser.SMOKE_PROJ / SMOKE_IMG with weight seeds (weight_seed, weight_seed + 1).
-    mid: the child saves every stored iterate too (out.npy -> out.npy + out.npy.mid.npz: proj [n,h,w], fbp [G,G], img [m,G,G])."""
+    mid: the child saves every stored iterate too (out.npy -> out.npy + out.npy.mid.npz: proj [n,h,w], fbp [G,G], img [m,G,G]).
+    img_only: `sino` is a [G,G] IMAGE and the child runs the image-domain half alone -- img_denoiser(mode="img_only") of the
+    reference harness (Utils/train_test_utils.py:482-550: the img loop, then the ultra loop if the option asks for it)."""
     import numpy as np
     draws = [np.asarray(d, dtype=np.float32).reshape(d.shape[-2], d.shape[-1]) for d in draws]
-    n_p = sum(1 for d in draws if d.shape == tuple(sino.shape))
-    assert all(d.shape == tuple(sino.shape) for d in draws[:n_p]) and all(d.shape != tuple(sino.shape) for d in draws[n_p:])
-    np.savez(path, sino=np.asarray(sino, dtype=np.float32), draws_p=np.stack(draws[:n_p]), draws_i=np.stack(draws[n_p:]),
-             opt=json.dumps({k: opt_dict[k] for k in OPT_KEYS}), weight_seed=weight_seed, sharpen_num=sharpen_num, dtype=dtype, nets=nets, mid=int(bool(mid)))
+    n_p = 0 if img_only else sum(1 for d in draws if d.shape == tuple(sino.shape))
+    assert img_only or (all(d.shape == tuple(sino.shape) for d in draws[:n_p]) and all(d.shape != tuple(sino.shape) for d in draws[n_p:]))
+    np.savez(path, sino=np.asarray(sino, dtype=np.float32), draws_p=np.stack(draws[:n_p]) if n_p else np.zeros((0,) + tuple(sino.shape), np.float32),
+             draws_i=np.stack(draws[n_p:]), img_only=int(bool(img_only)), opt=json.dumps({k: opt_dict[k] for k in OPT_KEYS}), weight_seed=weight_seed, sharpen_num=sharpen_num, dtype=dtype, nets=nets, mid=int(bool(mid)))
 
 
 def cpu_blocks(njobs, threads):
@@ -86,6 +88,21 @@ def main():
     sd_p = {k: torch.from_numpy(v).to(dt) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_p), seed=seed).items()}
     sd_i = {k: torch.from_numpy(v).to(dt) for k, v in synth.synth_state_dict(ou.param_shapes(cfg_i), seed=seed + (1 if smoke else 0)).items()}
     draws = iter([torch.from_numpy(d)[None, None].to(dt) for d in j["draws_p"]] + [torch.from_numpy(d)[None, None].to(dt) for d in j["draws_i"]])
+    if "img_only" in j.files and int(j["img_only"]):
+        from oracle import diffusion as od
+        x = torch.from_numpy(j["sino"])[None, None].to(dt)
+        sch = od.Schedule(opt["timesteps_img"], opt["schedule_power_img"])
+        eps = lambda xx, t: ou.unet_forward(cfg_i, sd_i, xx, t)   # noqa: E731
+        kw = dict(clip=opt["clip_img"], lambda_ratio=opt["lambda_ratio_img"], mode="img", noise_fn=lambda: next(draws), ldct=x,
+                  kernel_size=opt["kernel_size_img"], amplitude=opt["amplitude_img"], noise_strength_in=None)
+        res, _ = od.guided_reverse_process_slice(sch, eps, x, t_start=opt["t_start_img"], eta=opt["eta_img"],
+                                                 constant_guidance=opt["constant_guidance_img"], **kw)
+        if opt["ultra_img_denoise"]:
+            res_u, _ = od.guided_reverse_process_slice(sch, eps, res[-1], t_start=[5, 5, 5], eta=0.6, constant_guidance=0.6, **kw)
+            res = res + res_u
+        assert next(draws, None) is None, "the oracle consumed fewer draws than the device recorded"
+        np.save(out, res[-1].numpy())
+        return
     want, mid = op.progressive_slice(opt, cfg_p, sd_p, cfg_i, sd_i, torch.from_numpy(j["sino"])[None, None].to(dt),
                                    lambda: next(draws), sharpen_num=int(j["sharpen_num"]))
     assert next(draws, None) is None, "the oracle consumed fewer draws than the device recorded"

@@ -1871,6 +1871,39 @@ def _full_size_submit(pool):
     return runs
 
 
+C2_SLICE = 5        # the slice of the batch of eight that the CPU oracle replays
+
+
+def _config_c2_submit(pool):
+    """BASELINE config C2 at its literal setting: a batch of EIGHT 512x512 low-dose images (global slice ids 0..7), image domain
+    only, t_start_img=[15], constant guidance, no ultra pass, the production image UNet -- through the drop-in
+    img_denoiser(mode="img_only") (Utils/train_test_utils.py:482-550)."""
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser, _RecordingNoise
+    from ipdm_pytorch_amd.diffusion import NoiseSource
+    from tests import _oracle_child as oc
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    cfg_load(dict(device=DEV, mode="test_img", t_start_img=[15], ultra_img_denoise=False), opt.__dict__)
+    x = np.stack([synth.rasterize(synth.ellipse_phantom(b)) + 0.004 * synth.hash_normal((512, 512), 500 + b) for b in range(8)]).astype(np.float32)
+    den = progressive_domain_denoiser(opt, seed=77)
+    den.noise = _RecordingNoise(NoiseSource(77, 0))
+    got = den.img_denoiser(torch.from_numpy(x)[:, None], noise_strength=None, mode="img_only").cpu().numpy()
+    b = C2_SLICE
+    job = pool.path("c2_slice%d.npz" % b)
+    oc.write_job(job, opt.__dict__, x[b], [z[b:b + 1].cpu().numpy() for z in den.noise.draws], 0, 70, img_only=True)
+    h = pool.submit("C2 slice %d f32" % b, job, 3)
+    # a batch is its slices: the replayed slice and one more, each sampled alone on the device (global slice id kept), bit for bit
+    alone = {}
+    for s_id in (b, 0):
+        one = progressive_domain_denoiser(opt, seed=77, slice_id0=s_id)
+        alone[s_id] = one.img_denoiser(torch.from_numpy(x[s_id:s_id + 1])[:, None], noise_strength=None, mode="img_only").cpu().numpy()
+        del one
+    del den
+    torch.cuda.empty_cache()
+    return dict(got=got, h=h, alone=alone)
+
+
 # ---- device halves, in the order the pool should start their replays: the longest first
 @pytest.mark.oracle_submit
 def test_headline_configuration_device_run(oracle_pool):
@@ -1889,10 +1922,32 @@ def test_full_size_pipeline_device_run(oracle_pool):
 
 
 @pytest.mark.oracle_submit
+def test_config_c2_device_run(oracle_pool):
+    """Device half of test_config_c2_batch_of_eight_img_only."""
+    st = _once(oracle_pool, "c2", _config_c2_submit)
+    assert st["got"].shape == (8, 1, 512, 512) and np.isfinite(st["got"]).all()
+    for s_id, a in st["alone"].items():
+        assert np.array_equal(a, st["got"][s_id:s_id + 1]), (s_id, float(np.abs(a - st["got"][s_id:s_id + 1]).max()))
+
+
+@pytest.mark.oracle_submit
 def test_smoke_pipeline_device_runs(oracle_pool):
     """Device half of the three reduced-pipeline tests (PSNR of the canonical seed, stage-by-stage arbiter, arbiter over the seeds)."""
     runs = _once(oracle_pool, "reduced", _reduced_submit)
     assert len(runs) == len(REDUCED_SEEDS) and all(r["out"].shape == (1, 1, 512, 512) and np.isfinite(r["out"]).all() for r in runs)
+
+
+@pytest.mark.oracle_join
+def test_config_c2_batch_of_eight_img_only(oracle_pool):
+    """BASELINE.json config C2 ("Batch=8 512x512 slices, image-domain UNet only, t_start_img=[15]") against the CPU oracle: the
+    production image UNet, 15 network evaluations per slice, no ultra pass.  Slice C2_SLICE of the batch is replayed by the
+    oracle with the device's draws (max-abs 1e-4 relative, PSNR within 1e-4 relative: north_star); that slice and slice 0 equal
+    their single-slice runs bit for bit (checked by the device half), so every slice is what the reference's one-slice-at-a-time
+    call (Utils/train_test_utils.py:290-294) defines."""
+    st = _once(oracle_pool, "c2", _config_c2_submit)
+    want = oracle_pool.result(st["h"])
+    rep = _check_full_size(st["got"][C2_SLICE:C2_SLICE + 1], want, C2_SLICE, FULL_SIZE_MAX_REL)
+    print("config C2 B=8 img-only t_start_img=[15]: slice %d vs CPU oracle max-abs %.3e rms %.3e PSNR hip %.4f / cpu %.4f dB" % ((C2_SLICE,) + rep))
 
 
 @pytest.mark.oracle_join
