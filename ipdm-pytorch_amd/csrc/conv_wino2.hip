@@ -324,15 +324,24 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
         }
         if (a_bord) {
             const unsigned vm = pl ? a_vmp : a_vm;
+            if (IPDM_WINO2_BMASK) {
+                // bit e of the lane's mask, sign-extended: 0 / ~0 (volatile: not to be hoisted into eight live registers).  On SCALARS: a
+                // bit_cast of `d[e >> 1][e & 1]` in this unrolled loop was compiled as component 0 of the UPDATED vector for the odd
+                // elements (round 6: 46 GPU tests red; the same compiler behaviour as NOTEBOOK.md round 5, `tools/experiments/dbg_up2.py`)
+                float f[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (IPDM_WINO2_BMASK) {      // bit e of the lane's mask, sign-extended: 0 / ~0 (volatile: not to be hoisted into eight live registers)
+                for (int e = 0; e < 8; ++e) f[e] = d[e >> 1][e & 1];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
                     int keep;
                     asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(vm), "n"(e));
-                    d[e >> 1][e & 1] = __builtin_bit_cast(float, __builtin_bit_cast(int, d[e >> 1][e & 1]) & keep);
-                } else {
-                    d[e >> 1][e & 1] = (vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
+                    f[e] = __builtin_bit_cast(float, __builtin_bit_cast(int, f[e]) & keep);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = f32x2{f[2 * e], f[2 * e + 1]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e >> 1][e & 1] = (vm >> e & 1) ? d[e >> 1][e & 1] : 0.0f;
             }
         }
         if (pl) {            // every other window column: the de-interleaved half of the scratch row
