@@ -66,6 +66,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef IPDM_WINO2_BMASK
 #define IPDM_WINO2_BMASK 1          // 1 (round 6): the border tiles' per-element zeroing as v_bfe_i32 + v_and_b32 on the lane's bit mask instead of eight
 #endif                              //    v_cndmask on eight 64-bit SGPR masks recomputed per tile (sixteen SGPRs held through the chunk loop -> spills)
+#ifndef IPDM_WINO2_PRIO
+#define IPDM_WINO2_PRIO 0           // round 6 experiment: 1 = the wave's issue priority raised (s_setprio 2) over its 64 MFMAs of a chunk, 2 = over its
+#endif                              //    staging / transform instead (the two waves of a SIMD share the vector ALU: who wins the issue slot when both are ready)
 #ifndef IPDM_CONV_STAMPS
 #define IPDM_CONV_STAMPS 0          // `make stamps`: in-kernel s_memtime stamps of the phases (a stamped build changes what it measures)
 #endif
@@ -521,8 +524,11 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
             if (ch == nchunks - 2 && k + 1 < n_my) describe(k + 1);      // before the first loads of the next tile
             if (!(IPDM_WINO2_KO & 8)) issue_raw(ch2);          // raw(s + 2), consumed one iteration from now
         };
+        if (IPDM_WINO2_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         if (!late) stage_next();
+        if (IPDM_WINO2_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         IPDM_STAMP(0)
+        if (IPDM_WINO2_PRIO == 1) __builtin_amdgcn_s_setprio(2);
         const float *stage = lds + (s & 1) * V_FLOATS;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {                   // the two 8-channel sub-chunks of the staged chunk
@@ -564,7 +570,10 @@ __global__ void __launch_bounds__(512) conv_wino2_kernel(ConvArgs a, int ntiles)
             }
         }
         IPDM_STAMP(1)
+        if (IPDM_WINO2_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (IPDM_WINO2_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         if (!late && !(IPDM_WINO2_KO & 2)) transform_patch((s + 1) & 1);      // V(s + 1); that stage was last read by chunk s - 1
+        if (IPDM_WINO2_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         IPDM_STAMP(2)
         __syncthreads();                                   // V(s + 1) complete; every wave is done with V(s)
         IPDM_STAMP(3)

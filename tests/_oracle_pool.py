@@ -68,7 +68,7 @@ class OraclePool:
             # one core in every `stride`: the budgeted threads spread over the sockets' core complexes (their L3s and boost headroom)
             stride = max(1, len(phys) // budget)
             spread = phys[::stride][:budget]
-            self.main_cores, self.free = spread[-reserve_main:], spread[:budget - reserve_main]
+            self.main_cores, self.free = spread[budget - reserve_main:], spread[:budget - reserve_main]
             self.shared = False
         else:               # a small host (the CPU container): no reservation, at most two jobs at a time share what there is
             self.main_cores, self.free, self.shared = list(phys), list(phys), True
