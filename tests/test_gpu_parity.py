@@ -225,6 +225,25 @@ def test_randn_statistics_and_shard_invariance():
     assert torch.isfinite(NoiseSource(1).next_like(odd)).all()
 
 
+def test_randn_against_the_cpu_restatement():
+    """ipdm_randn against oracle/noise.py (Philox4x32-10 keyed by seed, GLOBAL slice id, draw index, element quad; Box-Muller in
+    float32): the key layout is exact -- one wrong word of the counter gives unrelated values --, the float32 transform agrees to
+    a few ulps of logf / sincosf (4e-6 relative to max(1, |z|)).  Cases: the two tensor shapes of the path, a count that is not
+    a multiple of 4, slice ids and draw indices beyond 32 bits, a 64-bit seed."""
+    from ipdm_pytorch_amd.diffusion import NoiseSource
+    from oracle import noise
+    for seed, slice0, draw, shape in ((7, 0, 0, (2, 1, 512, 512)), (1234, 5, 44, (2, 1, 2000, 912)), (3, 1, 2, (3, 1, 7, 5)),
+                                      ((1 << 40) + 17, (1 << 33) + 2, (1 << 32) + 9, (2, 1, 64, 48))):
+        src = NoiseSource(seed=seed, slice_id0=slice0)
+        src.draw = draw
+        got = src.next_like(torch.empty(shape, device=DEV)).cpu().numpy()
+        n = int(np.prod(shape[1:]))
+        for b in range(shape[0]):
+            want = noise.randn(seed, slice0 + b, draw, n)
+            err = np.abs(got[b].reshape(-1) - want) / np.maximum(1.0, np.abs(want))
+            assert err.max() <= 4e-6, (seed, slice0 + b, draw, float(err.max()))
+
+
 def test_slice_median():
     from ipdm_pytorch_amd import _lib
     for n in (1, 2, 7, 1000, 1824000, 262144):
@@ -1845,7 +1864,8 @@ HEADLINE_OVER = dict(t_start_proj=[15, 15, 15], t_start_img=[15], ultra_img_deno
 def _headline_submit(pool):
     from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
     from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser
-    got, h32, _ = _full_size_run(pool, HEADLINE_OVER, 1234, [0, 1], "headline", replay=[1], threads=9)
+    # (the longest replay: ~64 % of the pool's threads -- nine of the fourteen a 16-CPU box leaves for replays --, at most 32)
+    got, h32, _ = _full_size_run(pool, HEADLINE_OVER, 1234, [0, 1], "headline", replay=[1], threads=max(2, min(32, int(pool.capacity * 0.64 + 0.5))))
     opt = default_cfg([])
     cfg_load(mayo_test_options(), opt.__dict__)
     cfg_load(dict(HEADLINE_OVER, device=DEV), opt.__dict__)
