@@ -2,10 +2,12 @@
 # Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>_*  (copy the summaries you want judged into profiles/)
 # Counters are collected in their own passes (--pmc with --kernel-trace only), never with --stats.
+# (the traced bench runs two warm-up and two timed steps: its line then carries `clock`, the shader clock the box held -- the boxes of
+#  the pool differ by up to 6 % --, and the kernel statistics average over five steps: 2 + 2 + the untimed profiling step)
 TAG=${1:-r02}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-extra-legs > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt --no-extra-legs > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
 python3 tools/rocpd_summary.py $(find $OUT/${TAG}_trace -name "*.db" | head -1) $OUT/${TAG}_bench_b8
 # HBM traffic of every kernel (per-launch averages): two separate counter passes.  A counter pass serialises every
 # dispatch (a full step of 23k launches takes > 25 minutes), so the passes run a step with the same 3 : 2 mix of proj and
