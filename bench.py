@@ -612,6 +612,35 @@ def main():
                 del den3
             finally:
                 _lib.set_option("conv_no_up2", 0)
+            # the OPT-IN evaluation of the wide 3x3 layers (conv_wino3.hip, option conv_bf16x3): their Winograd-domain products on the
+            # bf16 matrix pipe through an error-free three-way split of both operands, float32 accumulate -- not the headline's arithmetic
+            torch.cuda.empty_cache()
+            _lib.set_option("conv_bf16x3", 1)
+            try:
+                den4 = progressive_domain_denoiser(opt, seed=1234, slice_id0=lo)
+                den4.data_sample_load(ldproj=ldproj)
+                out4 = den4.progressive_denoiser_device(sharpen_num=70)
+                den4.noise = NoiseSource(1234, lo)
+                den4.noise.draw = draw0
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                out4 = den4.progressive_denoiser_device(sharpen_num=70)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                assert den4.noise.draw - draw0 == draws_per_step, "bf16x3 leg consumed a different draw range"
+                d = (out4 - out).float()
+                mse = float((d * d).mean())
+                rng = float(out.max() - out.min())
+                line["alt_modes"]["IPDM_CONV_BF16X3=1"] = {
+                    "value": round(n_global / dt, 5), "unit": "slices/s", "ms_per_step": round(dt * 1e3, 2), "steps": 1,
+                    "dtype": "f32 activations and accumulation; the wide 3x3 layers' products as bf16 x 3 error-free splits on the bf16 matrix pipe (six of nine products)",
+                    "psnr_vs_default_db": round(10 * math.log10(rng * rng / mse), 2) if mse > 0 else None,
+                    "max_abs_vs_default": round(float(d.abs().max()), 8), "output_range": round(rng, 6),
+                    "note": "opt-in (conv_wino3.hip): never the headline; held to the same gates as the default path by "
+                            "tests/test_gpu_parity.py::test_full_size_pipeline_bf16x3_alt_mode and test_wino3_bf16x3_against_the_f32_kernels"}
+                del den4
+            finally:
+                _lib.set_option("conv_bf16x3", 0)
         if not args.no_cpu_baseline and world == 1:
             tb, used, cores = cpu_baseline()
             per_slice = n_fwd_proj * tb["proj"] + n_fwd_img * tb["img"] + tb["fbp"]

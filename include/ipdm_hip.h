@@ -42,7 +42,7 @@ int ipdm_abi_version(void);
  * README.md lists them.  Every switch starts from the environment variable IPDM_<NAME> (read once, kept
  * as a debug alias) and changes only through this call afterwards.  Switches that shape packed weights or kernel choice
  * are recorded by ipdm_unet_create: a forward on a handle created under other values fails with IPDM_ERR_INVALID instead
- * of running on a mismatched layout; per-call switches (conv_no_up2, conv_no_wup2, conv_no_wino, conv_no_pw, pw_item, pw_force, wino_v1, wino2_min_tiles, conv1x1_no_quarter, conv_nm, direct_no_skip_fuse, gn_unfused,
+ * of running on a mismatched layout; per-call switches (conv_no_up2, conv_no_wup2, conv_no_wino, conv_bf16x3, conv_no_pw, pw_item, pw_force, wino_v1, wino2_min_tiles, conv1x1_no_quarter, conv_nm, direct_no_skip_fuse, gn_unfused,
  * gn_two_stage, unet_transpose, attn_no_zseq, conv_dbg, art_per_view: every weight form they choose between is packed, the workspace
  * need is re-queried per forward) may change under a live handle.  Returns IPDM_ERR_INVALID for an unknown name. */
 int ipdm_set_option(const char *name, int value);
@@ -297,6 +297,7 @@ int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
  *   9 = conv_wino2 with K slices + combine pass (the layers with too few tiles per sample)
  *   10 = conv_pw (wide 1x1 layers: the barrier-free pointwise kernel)
  *   11 = conv_wup2 (an Upsample's parity form in the Winograd F(2x2,2x2) domain; never for this plain shape)
+ *   12 = conv_wino3 (conv_wino2's layers under the opt-in option conv_bf16x3: products on the bf16 matrix pipe, 3-way split)
  *   -1 = bad argument.
  * Test aid (replaces nothing in the reference): a parity test asserts the kernel it believes it covers. */
 int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W);

@@ -51,6 +51,7 @@ enum Opt {
     OPT_UNET_TRANSPOSE,      // -1 automatic | 0 never | 1 always
     OPT_ATTN_NO_KVSPLIT, OPT_ATTN_LEGACY, OPT_ATTN_NO_ZSEQ,
     OPT_ART_PER_VIEW,
+    OPT_CONV_BF16X3,         // opt-in (round 6): conv_wino2's layers with the channel contraction on the bf16 matrix pipe, error-free 3-way split (conv_wino3.hip; per call)
     OPT_COUNT
 };
 int opt(Opt o);

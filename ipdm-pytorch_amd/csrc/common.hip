@@ -39,6 +39,7 @@ const OptDef g_opt_def[OPT_COUNT] = {
     {"unet_transpose", -1, true, -1, 1},
     {"attn_no_kvsplit", 0, false}, {"attn_legacy", 0, false}, {"attn_no_zseq", 0, true},
     {"art_per_view", 0, true},
+    {"conv_bf16x3", 0, true},
 };
 bool opt_value_ok(int i, int v)
 {

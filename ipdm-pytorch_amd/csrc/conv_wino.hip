@@ -38,6 +38,7 @@
 // value = 2 kp + lk: the four K steps of a lane are one ds_read_b128.  Plus 32 KB exchange, 2 KB statistics staging, 28 KB
 // producer scratch, 32 bytes of tile descriptors.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include "common.h"
 #include "unet_kernels.h"
@@ -737,10 +738,16 @@ bool conv_wino_shape_ok(int Cout, int Cin, int ks, int stride, int interleave)
 }
 
 // [chunk q][cout tile][xi][h][lk][cout 32][kp], xi = row_slot(i) * 4 + j: U = G g G^T in double, rounded once; channel = 8 q + 2 kp + lk
+// Layers conv_wino3.hip can take (whole 128-cout tiles, whole 16-channel chunks) get a second image behind the first: the same float32
+// values split into three bf16 terms by truncation (u = u1 + u2 + u3 exactly),
+// [16-channel chunk Q][128-cout tile][xi][term 3][cout quarter 4][k half 2][cout 32][8 x bf16], channel = 16 Q + 8 (k half) + element
 void conv_pack_weights_wino(const float *w, int Cout, int Cin, std::vector<float> &packed)
 {
     const int nq = (Cin + KC - 1) / KC, nct = Cout / BN;
-    packed.assign((size_t)nq * nct * U_CHUNK_FLOATS, 0.0f);
+    const bool with3 = Cout % 128 == 0 && Cin % 16 == 0;
+    const size_t f32_floats = (size_t)nq * nct * U_CHUNK_FLOATS, u3_block_halves = (size_t)16 * 3 * 4 * 2 * 32 * 8;
+    packed.assign(f32_floats + (with3 ? (size_t)(Cin / 16) * (Cout / 128) * u3_block_halves / 2 : 0), 0.0f);
+    unsigned short *u3 = reinterpret_cast<unsigned short *>(packed.data() + f32_floats);
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci) {
@@ -754,6 +761,21 @@ void conv_pack_weights_wino(const float *w, int Cout, int Cin, std::vector<float
                 for (int j = 0; j < 4; ++j) {
                     const double u = gg[i][0] * G[j][0] + gg[i][1] * G[j][1] + gg[i][2] * G[j][2];
                     base[(((((row_slot(i) * 4 + j) * 2 + hh) * 2 + lk) * 32 + cl) * 4) + kp] = (float)u;
+                    if (with3) {
+                        const float uf = (float)u;
+                        unsigned b1, b2, b3;
+                        float r1, r2;
+                        memcpy(&b1, &uf, 4); b1 &= 0xffff0000u;
+                        float t1; memcpy(&t1, &b1, 4); r1 = uf - t1;
+                        memcpy(&b2, &r1, 4); b2 &= 0xffff0000u;
+                        float t2; memcpy(&t2, &b2, 4); r2 = r1 - t2;
+                        memcpy(&b3, &r2, 4);
+                        const int Q = ci / 16, kb = (ci % 16) / 8, el = ci % 8, TT = co / 128, hq = (co % 128) / 32;
+                        unsigned short *blk = u3 + ((size_t)Q * (Cout / 128) + TT) * u3_block_halves;
+                        const unsigned terms[3] = {b1, b2, b3};
+                        for (int t = 0; t < 3; ++t)
+                            blk[((((size_t)((row_slot(i) * 4 + j) * 3 + t) * 4 + hq) * 2 + kb) * 32 + cl) * 8 + el] = (unsigned short)(terms[t] >> 16);
+                    }
                 }
         }
 }
@@ -785,7 +807,7 @@ int conv2d_wino_launch(const ConvArgs &args, hipStream_t st)
     IPDM_REQUIRE(a.ksplit == 1 || conv_wino2_eligible(a), "conv2d_wino: this layer cannot be split into %d K slices", a.ksplit);
     if (prof) prof_before(v2 ? 5 : 3, st);
     if (v2) {
-        if (int rc = conv2d_wino2_launch(a, st)) return rc;
+        if (int rc = conv_wino3_eligible(a) ? conv2d_wino3_launch(a, st) : conv2d_wino2_launch(a, st)) return rc;      // (conv_wino3: opt-in, option conv_bf16x3)
     } else if (a.x1_planar && res) hipLaunchKernelGGL((conv_wino_kernel<true, true>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
     else if (a.x1_planar) hipLaunchKernelGGL((conv_wino_kernel<true, false>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
     else if (res) hipLaunchKernelGGL((conv_wino_kernel<false, true>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);

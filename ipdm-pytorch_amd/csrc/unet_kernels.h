@@ -133,6 +133,8 @@ int conv2d_wino_launch(const ConvArgs &a, hipStream_t st);
 int conv_wino_split(const ConvArgs &a);            // K slices conv_wino2 would cut a K-split layer into (0: it cannot)
 bool conv_wino2_eligible(const ConvArgs &a);       // ... of those, the layers the round-4 kernel takes (whole 128-cout tiles, 16-channel chunks)
 int conv2d_wino2_launch(const ConvArgs &prepared, hipStream_t st);   // conv_wino2.hip; called by conv2d_wino_launch
+bool conv_wino3_eligible(const ConvArgs &prepared);                    // conv_wino3.hip: option conv_bf16x3 + conv_wino2's whole layers
+int conv2d_wino3_launch(const ConvArgs &prepared, hipStream_t st);   // ... called by conv2d_wino_launch in conv_wino2's place
 // [Cin/8][Cout/64][xi 16][cout half][k parity][cout 32][k step] = the LDS image of one (chunk, cout tile)
 void conv_pack_weights_wino(const float *w, int Cout, int Cin, std::vector<float> &packed);
 bool conv_ws_planar_ok(const ConvArgs &a);
