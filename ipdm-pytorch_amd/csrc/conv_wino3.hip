@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
         for (int t = 0; t < 3; ++t) bb[0][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + t * 1024);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            if (e == 4 && ch1 == 0) { w_co = g_co; w_q0 = g_ks * nchunks; }      // from here on the weights loaded belong to the item described last
+            if (e == 5 && ch1 == 0) { w_co = g_co; w_q0 = g_ks * nchunks; }      // from here on (the loads behind the MFMAs of e = 5, 6, 7: the NEXT chunk's positions 0-2) the weights belong to the item described last
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 a0 = __builtin_bit_cast(bf16x8, ua[e & 3][0]), a1 = __builtin_bit_cast(bf16x8, ua[e & 3][1]), a2 = __builtin_bit_cast(bf16x8, ua[e & 3][2]);
             const bf16x8 v0 = __builtin_bit_cast(bf16x8, bb[e & 1][0]), v1 = __builtin_bit_cast(bf16x8, bb[e & 1][1]), v2 = __builtin_bit_cast(bf16x8, bb[e & 1][2]);

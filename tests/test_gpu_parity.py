@@ -707,7 +707,10 @@ def test_wino_kernels_bit_identical(case):
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), (err, case)
 
 
-@pytest.mark.parametrize("case", WINO128_CASES)
+@pytest.mark.parametrize("case", WINO128_CASES + [
+    (8, 128, 0, 64, 64, 256, 0, False),      # two cout tiles AND several rounds per workgroup: consecutive tiles of a workgroup switch weight tiles
+    (8, 256, 0, 64, 64, 256, 2, True),       # (the first version took the new tile's weights for the last position of the old tile's last chunk)
+])
 def test_wino3_bf16x3_against_the_f32_kernels(case):
     """conv_wino3 (opt-in, option conv_bf16x3): conv_wino2's layers with the channel contraction on the bf16 matrix pipe through an
     error-free three-way split of both operands (six products, float32 accumulate).  Not the bits of the f32 kernels -- another
@@ -808,6 +811,19 @@ def test_wino2_run_to_run_determinism():
         bad, first, ref = _conv3x3_repeats(*case, reps=12)
         assert bad == 0, case
         assert ref is None or torch.equal(ref, first), case
+
+
+def test_wino3_fused_statistics_and_planar_reader():
+    """conv_wino3 as the PRODUCER of fused GroupNorm statistics (conv A -> GroupNorm+SiLU -> conv B, both on conv_wino3 where
+    eligible) and as the READER of a parity-planar x1 (the up2 -> concat -> conv chain): each against the torch ops, 2e-5."""
+    from ipdm_pytorch_amd import _lib
+    with _lib.option("conv_bf16x3", 1), _lib.option("wino2_min_tiles", 1):
+        for case in [(2, 64, 80, 64, 128, 3, 1, True, 2, 128), (1, 128, 72, 57, 256, 3, 1, True, 2, 128), (2, 128, 26, 250, 128, 3, 1, True, 2, 128),
+                     (8, 128, 64, 64, 128, 3, 1, True, 2, 256)]:
+            _conv_gn_conv(case)
+        for case in UP2_CASES:
+            if case[6] % 128 == 0 and case[7] == 3:
+                _up_conv_chain(case)
 
 
 def test_wino3_run_to_run_determinism():
