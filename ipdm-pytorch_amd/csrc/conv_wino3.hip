@@ -63,6 +63,12 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef IPDM_WINO3_STAGGER
 #define IPDM_WINO3_STAGGER 1        // 1: waves 0-3 stage / transform before their MFMAs, waves 4-7 after (0: every wave stages first)
 #endif
+#ifndef IPDM_WINO3_BBUF
+#define IPDM_WINO3_BBUF 2
+#endif
+#ifndef IPDM_WINO3_PACK
+#define IPDM_WINO3_PACK 0           // 1: V stored as dwords (the lane pair's two halfwords brought together by v_permlane32_swap) instead of 48 two-byte stores per lane
+#endif
 #ifndef IPDM_WINO3_DBG
 #define IPDM_WINO3_DBG 0            // debugging arms: 1 = V stored as whole dwords (the lane pair's two halfwords merged through a shuffle), 2 = a barrier in
 #endif                              //    front of the transform, 4 = every chunk starts with all loads landed
@@ -375,7 +381,8 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
     const int odd = l31 >> 4, ty = l31 & 1, txh = (l31 & 15) >> 1;
     f32x16 acc[8];
     f32x4 ua[4][3];                                        // the A operands (the three bf16 terms of U) of FOUR positions: ring, reloaded three positions ahead
-    f32x4 bb[2][3] = {};                                   // the B operands (the three bf16 terms of V) of positions e (slot e & 1) and e + 1
+    constexpr int NB = IPDM_WINO3_BBUF;                    // V operand buffers: 2 = position e + 1 goes into the registers of e - 1, 3 = of e - 2 (two accumulate chains behind them)
+    f32x4 bb[NB == 3 ? 4 : 2][3] = {};                     // the B operands (the three bf16 terms of V); with three buffers slot = position % 4 over 0, 1, 2, 3 -> ring of FOUR (8 % 4 == 0: static indices)
     const int out_plane = a.Ho * a.Wo;
     const int plane4 = out_plane * 4;
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
@@ -453,6 +460,37 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
                 o[rs * 4 + 3] = tt[i * 4 + pcol[1]] - tt[i * 4 + pcol[3]];
             }
         }
+        if (IPDM_WINO3_PACK) {
+            // Two positions at a time: the lanes l (channel 2 w) and l + 32 (channel 2 w + 1) hold the two halfwords of one dword of the tile's
+            // operand cell.  v_permlane32_swap puts both halfwords of position x into the lower lane and both of position x + 1 into the upper
+            // one; v_perm_b32 packs them: 24 dword stores per lane and chunk instead of 48 halfword ones.
+            char *vdp = ldsb + stage_off(par) + (swave >> 2) * 512 + v_slot * 16 + (swave & 3) * 4 + (lk ? 3 * 1024 : 0);
+#pragma unroll
+            for (int x = 0; x < 16; x += 2) {
+                unsigned ta[3], tb[3];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float v = o[x + q];
+                    const unsigned b1 = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
+                    const float r1 = v - __builtin_bit_cast(float, b1);
+                    const unsigned b2 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+                    const float r2 = r1 - __builtin_bit_cast(float, b2);
+                    unsigned *t = q ? tb : ta;
+                    t[0] = b1; t[1] = b2; t[2] = __builtin_bit_cast(unsigned, r2);
+                }
+                // (s_nop 1: the swap reads need two wait states after the VALU writes; after it ta = the even channel's term, tb = the odd one's,
+                //  of position x in lanes 0-31 and of position x + 1 in lanes 32-63)
+                asm("s_nop 1\n\t"
+                    "v_permlane32_swap_b32 %0, %3\n\t"
+                    "v_permlane32_swap_b32 %1, %4\n\t"
+                    "v_permlane32_swap_b32 %2, %5"
+                    : "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2]), "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]));
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    *reinterpret_cast<unsigned *>(vdp + (x * 3 + t) * 1024) = __builtin_amdgcn_perm(tb[t], ta[t], 0x07060302u);
+            }
+            return;
+        }
         char *vd = ldsb + stage_off(par) + v_lane_b;
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
@@ -489,9 +527,6 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
     // ---------------------------------------------------------------- prologue: tile 0, chunk 0 staged, chunk 1 in flight
     describe(0);
     a_vm = g_vm; a_vmp = g_vmp; a_lsh = g_lsh; a_bord = g_bord;
-    w_co = g_co; w_q0 = g_ks * nchunks;
-#pragma unroll
-    for (int e = 0; e < 3; ++e) issue_u(e, 0);
     issue_raw(0);
     if (ih == 0) fetch_bias(g_co * BN);
     activate();
@@ -550,6 +585,14 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
             stage_next();
             if (!(IPDM_WINO2_KO & 2)) { read_patch(); transform_patch((s + 1) & 1); }
         };
+        if (FIRST) {
+            // the U terms of the tile's first three positions: NOT prefetched across the epilogue of the tile before (the ring's 36 registers
+            // are free there: with them held, the instantiations that add a residual spilled 52 vector registers and lost the kernel's gain);
+            // waves 0-3 cover the latency with their staging, waves 4-7 pay it once per tile
+            w_co = cur.co0 / BN; w_q0 = cur.ks * nchunks;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) issue_u(e, 0);
+        }
         if (early) stage_all();
         IPDM_STAMP(0)
         const char *stage = ldsb + stage_off(s & 1);
@@ -565,12 +608,16 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
         // of the staging / transform of waves 4-7 lands in them (IPDM_WINO3_DRAIN > 0: a timed drain in addition).
 #pragma unroll
         for (int t = 0; t < 3; ++t) bb[0][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + t * 1024);
+        constexpr int BM = NB == 3 ? 3 : 1;               // slot mask
+        if (NB == 3) {                                     // ... and position 1 (into the slot of the previous chunk's position 5)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bb[1][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + (3 + t) * 1024);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            if (e == 5 && ch1 == 0) { w_co = g_co; w_q0 = g_ks * nchunks; }      // from here on (the loads behind the MFMAs of e = 5, 6, 7: the NEXT chunk's positions 0-2) the weights belong to the item described last
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 a0 = __builtin_bit_cast(bf16x8, ua[e & 3][0]), a1 = __builtin_bit_cast(bf16x8, ua[e & 3][1]), a2 = __builtin_bit_cast(bf16x8, ua[e & 3][2]);
-            const bf16x8 v0 = __builtin_bit_cast(bf16x8, bb[e & 1][0]), v1 = __builtin_bit_cast(bf16x8, bb[e & 1][1]), v2 = __builtin_bit_cast(bf16x8, bb[e & 1][2]);
+            const bf16x8 v0 = __builtin_bit_cast(bf16x8, bb[e & BM][0]), v1 = __builtin_bit_cast(bf16x8, bb[e & BM][1]), v2 = __builtin_bit_cast(bf16x8, bb[e & BM][2]);
             // the small products first
             if (FIRST) {
                 const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -578,7 +625,7 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
                 // (with C = 0 the accumulator is dead in front of this instruction, and this compiler placed the B operand that dies
                 //  here INSIDE the destination's sixteen registers -- `v_mfma_f32_32x32x16_bf16 v[64:79], v[96:99], v[76:79], 0` --:
                 //  the f32 MFMA's destination is early-clobber in LLVM, this gfx950 instruction's is not: keep the operand alive past it)
-                asm volatile("" ::"v"(bb[e & 1][2]), "v"(ua[e & 3][0]));
+                asm volatile("" ::"v"(bb[e & BM][2]), "v"(ua[e & 3][0]));
             } else {
                 acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, v2, acc[e], 0, 0, 0);
             }
@@ -589,12 +636,24 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
             acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, v0, acc[e], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             // behind them: the V terms of position e + 1 into the registers of position e - 1 ...
-            if (e + 1 < 8) {
+            // (every reload is preceded by an empty asm USE of the registers' old contents: between the MFMAs that read them last and
+            //  this point the allocator must not hand them to a temporary -- a VALU write there lands inside the window in which the
+            //  queued MFMA still reads them; that was the rare residue after the reordering alone)
+            if (NB == 3) {                                     // position e + 2 into the registers of position e - 2
+                asm volatile("" ::"v"(bb[(e + 2) & 3][0]), "v"(bb[(e + 2) & 3][1]), "v"(bb[(e + 2) & 3][2]));
+                if (e + 2 < 8) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) bb[(e + 2) & 3][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + ((e + 2) * 3 + t) * 1024);
+                }
+            } else if (e + 1 < 8) {
+                asm volatile("" ::"v"(bb[(e + 1) & 1][0]), "v"(bb[(e + 1) & 1][1]), "v"(bb[(e + 1) & 1][2]));
 #pragma unroll
                 for (int t = 0; t < 3; ++t) bb[(e + 1) & 1][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + ((e + 1) * 3 + t) * 1024);
             }
             // ... and the U terms of position e + 3 (this chunk's, or the next chunk's e - 5) into ring slot (e - 1) & 3
-            if (e + 3 < 8) issue_u(e + 3, ch); else issue_u(e - 5, ch1);
+            asm volatile("" ::"v"(ua[(e + 3) & 3][0]), "v"(ua[(e + 3) & 3][1]), "v"(ua[(e + 3) & 3][2]));
+            if (e + 3 < 8) issue_u(e + 3, ch);
+            else if (ch + 1 < nchunks) issue_u(e - 5, ch + 1);          // (the next TILE's first positions: at its first chunk)
             __builtin_amdgcn_sched_barrier(0);
         }
         // drain: the transform's temporaries (and the next chunk's staging) may take the registers of the last position's operands
@@ -606,7 +665,8 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
         // (the registers of the last position -- bb[1], ring slot 3 -- stay reserved up to here: its accumulate chain may still have been
         //  waiting in the matrix unit while the staging of waves 4-7 looked for temporaries; waves 0-3 go from their MFMAs to the barrier,
         //  where they wait for that staging -- an order of magnitude longer than a chain)
-        asm volatile("" ::"v"(bb[1][0]), "v"(bb[1][1]), "v"(bb[1][2]), "v"(ua[3][0]), "v"(ua[3][1]), "v"(ua[3][2]));
+        asm volatile("" ::"v"(bb[NB == 3 ? 3 : 1][0]), "v"(bb[NB == 3 ? 3 : 1][1]), "v"(bb[NB == 3 ? 3 : 1][2]), "v"(ua[3][0]), "v"(ua[3][1]), "v"(ua[3][2]));
+        if (NB == 3) asm volatile("" ::"v"(bb[2][0]), "v"(bb[2][1]), "v"(bb[2][2]));
         IPDM_STAMP(2)
         __syncthreads();                                   // V(s + 1) complete; every wave is done with V(s)
         IPDM_STAMP(3)
