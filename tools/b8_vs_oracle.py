@@ -69,6 +69,10 @@ def main():
         worst = [max(worst[0], float(err.max())), max(worst[1], abs(p_hip - p_cpu) / abs(p_cpu))]
         lines.append("slice %d: max-abs %.3e rms %.3e (scale %.3f) | PSNR hip %.5f dB / oracle %.5f dB (rel %.1e) | %s" % (
             b, err.max(), float(np.sqrt((err ** 2).mean())), scale, p_hip, p_cpu, abs(p_hip - p_cpu) / abs(p_cpu), "ok" if good else "OUT OF BOUND"))
+        big = np.argwhere(err[0, 0] > 5e-5 * scale)
+        if len(big):      # where: a localized streak (a guidance-map block across the jump of weight_lambda) or spread over the image?
+            lines.append("         %d pixels above 5e-5: rows %d..%d, columns %d..%d; the 99.9th percentile of |err| is %.2e" % (
+                len(big), big[:, 0].min(), big[:, 0].max(), big[:, 1].min(), big[:, 1].max(), float(np.quantile(err, 0.999))))
     lines.append("worst: max-abs %.3e (bound 1e-4 x scale), PSNR relative difference %.1e (bound 1e-4): %s" % (worst[0], worst[1], "ALL WITHIN BOUNDS" if ok else "FAILED"))
     lines.append(pool.report())
     out_dir = os.path.join(ROOT, "gpurun_out")
