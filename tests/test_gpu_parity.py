@@ -827,11 +827,10 @@ def test_wino3_fused_statistics_and_planar_reader():
 
 
 def test_wino3_run_to_run_determinism():
-    """conv_wino3 (option conv_bf16x3) under repetition, the test that found its hazard: a v_mfma_f32_32x32x16_bf16 waiting in the
-    matrix unit behind its accumulate chain reads its A / B registers when it STARTS; a load issued behind the chain that returns
-    into them first corrupts one output row of a tile in ~1 of 100 tiles, run-dependently (NOTEBOOK.md round 6).  Shapes with one
-    tile per workgroup and with many rounds, ragged edges, concat, residual; sixty launches each, every run bit-equal to the
-    first, and the first within 2e-5 of conv_wino2."""
+    """conv_wino3 (option conv_bf16x3) under repetition -- the kind of test that found its first version wrong: with conv_wino2's load
+    order one output row of a tile came out as garbage in ~1 of 100 tiles, run-dependently (cause unidentified; the shipped order and
+    the pinned operand registers are an empirical fix: NOTEBOOK.md round 6).  Shapes with one tile per workgroup and with many rounds,
+    ragged edges, concat, residual; sixty launches each, every run bit-equal to the first, and the first within 2e-5 of conv_wino2."""
     from ipdm_pytorch_amd import _lib
     for case in [(2, 128, 0, 37, 145, 128, 2, True), (1, 128, 0, 130, 250, 128, 2, True), (2, 128, 0, 36, 144, 128, 0, False),
                  (2, 64, 64, 45, 95, 128, 1, True), (8, 128, 0, 128, 128, 128, 2, True), (3, 128, 16, 40, 104, 128, 2, True)]:
