@@ -591,9 +591,11 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
             // waves 0-3 cover the latency with their staging, waves 4-7 pay it once per tile
             w_co = cur.co0 / BN; w_q0 = cur.ks * nchunks;
 #pragma unroll
-            for (int e = 0; e < 3; ++e) issue_u(e, 0);
+            for (int e = 0; e < ((IPDM_WINO3_DBG & 2048) ? 4 : 3); ++e) issue_u(e, 0);
         }
-        if (early) stage_all();
+        constexpr bool OLD = (IPDM_WINO3_DBG & 4096) != 0;      // (debugging arm: the FIRST version's structure -- stage at the start, patch read at e = 4, transform at the end)
+        if (OLD) stage_next();
+        else if (early) stage_all();
         IPDM_STAMP(0)
         const char *stage = ldsb + stage_off(s & 1);
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -601,7 +603,8 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
         // from LDS in front of a position's MFMAs, U reloaded in place right behind them -- this kernel produced run-dependent garbage in one
         // output row of a tile in ~1 of 100 tiles; worse the longer a position's MFMA group took, gone with every accumulate chain drained
         // behind its position.  The suspected mechanism (a queued v_mfma_f32_32x32x16_bf16 reading its sources after a later write to them) does
-        // NOT reproduce in isolation (tools/ubench/mfma_src_window.hip): the cause is unidentified, the fix empirical -- nothing is loaded into
+        // NOT reproduce in isolation (tools/ubench/mfma_src_window.hip), and the old orders switched back on here (IPDM_WINO3_DBG 512 / 2048 / 4096)
+        // do not bring it back: the cause is neither identified nor isolated.  The order kept is the conservative one -- nothing is loaded into
         // the operand registers of position e before the six MFMAs of position e + 1 have been issued: the V terms of position e + 1 and the U
         // terms of position e + 3 (ring of four) go into the registers of position e - 1 BEHIND the MFMAs of e; every reload is preceded by an
         // empty asm use of the old contents (the registers are not handed to anything in between), and the last position's registers stay
@@ -615,6 +618,14 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+            if (OLD && e == 4) read_patch();
+            if (IPDM_WINO3_DBG & 512) {      // (debugging arm: the FIRST version's order for the V terms -- position e + 1 read in front of the MFMAs of e)
+                if (e + 1 < 8) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) bb[(e + 1) & 1][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + ((e + 1) * 3 + t) * 1024);
+                }
+                if (IPDM_WINO3_DBG & 1024) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 a0 = __builtin_bit_cast(bf16x8, ua[e & 3][0]), a1 = __builtin_bit_cast(bf16x8, ua[e & 3][1]), a2 = __builtin_bit_cast(bf16x8, ua[e & 3][2]);
             const bf16x8 v0 = __builtin_bit_cast(bf16x8, bb[e & BM][0]), v1 = __builtin_bit_cast(bf16x8, bb[e & BM][1]), v2 = __builtin_bit_cast(bf16x8, bb[e & BM][2]);
@@ -645,15 +656,20 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
 #pragma unroll
                     for (int t = 0; t < 3; ++t) bb[(e + 2) & 3][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + ((e + 2) * 3 + t) * 1024);
                 }
-            } else if (e + 1 < 8) {
+            } else if (e + 1 < 8 && !(IPDM_WINO3_DBG & 512)) {
                 asm volatile("" ::"v"(bb[(e + 1) & 1][0]), "v"(bb[(e + 1) & 1][1]), "v"(bb[(e + 1) & 1][2]));
 #pragma unroll
                 for (int t = 0; t < 3; ++t) bb[(e + 1) & 1][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + ((e + 1) * 3 + t) * 1024);
             }
             // ... and the U terms of position e + 3 (this chunk's, or the next chunk's e - 5) into ring slot (e - 1) & 3
-            asm volatile("" ::"v"(ua[(e + 3) & 3][0]), "v"(ua[(e + 3) & 3][1]), "v"(ua[(e + 3) & 3][2]));
-            if (e + 3 < 8) issue_u(e + 3, ch);
-            else if (ch + 1 < nchunks) issue_u(e - 5, ch + 1);          // (the next TILE's first positions: at its first chunk)
+            if (IPDM_WINO3_DBG & 2048) {      // (debugging arm: the FIRST version's order for the U terms -- position e + 4 IN PLACE right behind the MFMAs of e)
+                if (e < 4) issue_u(e + 4, ch);
+                else if (ch + 1 < nchunks) issue_u(e - 4, ch + 1);
+            } else {
+                asm volatile("" ::"v"(ua[(e + 3) & 3][0]), "v"(ua[(e + 3) & 3][1]), "v"(ua[(e + 3) & 3][2]));
+                if (e + 3 < 8) issue_u(e + 3, ch);
+                else if (ch + 1 < nchunks) issue_u(e - 5, ch + 1);          // (the next TILE's first positions: at its first chunk)
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // drain: the transform's temporaries (and the next chunk's staging) may take the registers of the last position's operands
@@ -661,7 +677,8 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
         for (int d = 0; d < IPDM_WINO3_DRAIN; ++d) asm volatile("s_nop 15");
         __builtin_amdgcn_sched_barrier(0);
         IPDM_STAMP(1)
-        if (!early) stage_all();
+        if (OLD) transform_patch((s + 1) & 1);
+        else if (!early) stage_all();
         // (the registers of the last position -- bb[1], ring slot 3 -- stay reserved up to here: its accumulate chain may still have been
         //  waiting in the matrix unit while the staging of waves 4-7 looked for temporaries; waves 0-3 go from their MFMAs to the barrier,
         //  where they wait for that staging -- an order of magnitude longer than a chain)
