@@ -682,7 +682,8 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
         // (the registers of the last position -- bb[1], ring slot 3 -- stay reserved up to here: its accumulate chain may still have been
         //  waiting in the matrix unit while the staging of waves 4-7 looked for temporaries; waves 0-3 go from their MFMAs to the barrier,
         //  where they wait for that staging -- an order of magnitude longer than a chain)
-        asm volatile("" ::"v"(bb[NB == 3 ? 3 : 1][0]), "v"(bb[NB == 3 ? 3 : 1][1]), "v"(bb[NB == 3 ? 3 : 1][2]), "v"(ua[3][0]), "v"(ua[3][1]), "v"(ua[3][2]));
+        if (!(IPDM_WINO3_DBG & 8192))
+            asm volatile("" ::"v"(bb[NB == 3 ? 3 : 1][0]), "v"(bb[NB == 3 ? 3 : 1][1]), "v"(bb[NB == 3 ? 3 : 1][2]), "v"(ua[3][0]), "v"(ua[3][1]), "v"(ua[3][2]));
         if (NB == 3) asm volatile("" ::"v"(bb[2][0]), "v"(bb[2][1]), "v"(bb[2][2]));
         IPDM_STAMP(2)
         __syncthreads();                                   // V(s + 1) complete; every wave is done with V(s)
