@@ -390,7 +390,8 @@ int conv_kernel_code(const ConvArgs &a)
         if (conv_up2_eligible(a)) return conv_wup2_eligible(a) ? 11 : 7;
         if (conv_wino_eligible(a)) {
             if (a.split_ws && conv_split(a) > 1) return 9;
-            return (!opt(OPT_WINO_V1) && conv_wino2_eligible(a)) ? (conv_wino3_eligible(a) ? 12 : 2) : 1;
+            if (conv_wino3_eligible(a)) return 12;
+            return (!opt(OPT_WINO_V1) && conv_wino2_eligible(a)) ? 2 : 1;
         }
         return (a.split_ws && conv_ws_split(a) > 1) ? 4 : 3;
     }

@@ -803,11 +803,12 @@ int conv2d_wino_launch(const ConvArgs &args, hipStream_t st)
     const void *fn = a.x1_planar ? (res ? (const void *)conv_wino_kernel<true, true> : (const void *)conv_wino_kernel<true, false>)
                                  : (res ? (const void *)conv_wino_kernel<false, true> : (const void *)conv_wino_kernel<false, false>);
     if (int rc = ensure_dynamic_lds(fn, LDS_BYTES)) return rc;
-    const bool prof = prof_enabled(), v2 = a.ksplit > 1 || (!opt(OPT_WINO_V1) && conv_wino2_eligible(a));
+    const bool v3 = conv_wino3_eligible(a);               // (opt-in, option conv_bf16x3: a rule of the layer alone)
+    const bool prof = prof_enabled(), v2 = v3 || a.ksplit > 1 || (!opt(OPT_WINO_V1) && conv_wino2_eligible(a));
     IPDM_REQUIRE(a.ksplit == 1 || conv_wino2_eligible(a), "conv2d_wino: this layer cannot be split into %d K slices", a.ksplit);
     if (prof) prof_before(v2 ? 5 : 3, st);
     if (v2) {
-        if (int rc = conv_wino3_eligible(a) ? conv2d_wino3_launch(a, st) : conv2d_wino2_launch(a, st)) return rc;      // (conv_wino3: opt-in, option conv_bf16x3)
+        if (int rc = v3 ? conv2d_wino3_launch(a, st) : conv2d_wino2_launch(a, st)) return rc;
     } else if (a.x1_planar && res) hipLaunchKernelGGL((conv_wino_kernel<true, true>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
     else if (a.x1_planar) hipLaunchKernelGGL((conv_wino_kernel<true, false>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);
     else if (res) hipLaunchKernelGGL((conv_wino_kernel<false, true>), dim3((unsigned)G), dim3(512), LDS_BYTES, st, a, (int)ntiles);

@@ -61,7 +61,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define IPDM_WINO3_DRAIN 0          // s_nop 15 statements (16 cycles each) between the last MFMA of a chunk and the transform: the last accumulate chain has left the matrix unit
 #endif
 #ifndef IPDM_WINO3_STAGGER
-#define IPDM_WINO3_STAGGER 1        // 1: waves 0-3 stage / transform before their MFMAs, waves 4-7 after (0: every wave stages first)
+#define IPDM_WINO3_STAGGER 0        // 0 (shipped): every wave stages / transforms chunk s + 1 first and multiplies chunk s after.  1: waves 4-7 multiply first
+                                    //    (x1.03 ... 1.05 faster; 3: every wave multiplies first; 4: the halves swapped) -- with ANY wave in the multiply-first order
+                                    //    the FIRST forward of a process came out wrong (one Winograd position of sixteen tiles of one workgroup tile, all couts,
+                                    //    1e-2 relative) in 30 ... 50 % of fresh processes on two of the boxes seen, never in later forwards, never with blocking
+                                    //    launches, never in this order (0 of 16 + 30 processes): NOTEBOOK.md round 6, tools/experiments/dbg_bf16x3_fwd.py.  Cause not identified.
 #endif
 #ifndef IPDM_WINO3_BBUF
 #define IPDM_WINO3_BBUF 2
@@ -70,8 +74,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define IPDM_WINO3_PACK 0           // 1: V stored as dwords (the lane pair's two halfwords brought together by v_permlane32_swap) instead of 48 two-byte stores per lane
 #endif
 #ifndef IPDM_WINO3_DBG
-#define IPDM_WINO3_DBG 0            // debugging arms: 1 = V stored as whole dwords (the lane pair's two halfwords merged through a shuffle), 2 = a barrier in
-#endif                              //    front of the transform, 4 = every chunk starts with all loads landed
+#define IPDM_WINO3_DBG 0            // debugging arms: 1 = V stored as whole dwords (the lane pair's two halfwords merged through a shuffle), 16 = a barrier at the top of
+#endif                              //    every chunk and in front of the epilogue, 32 = every chunk and the epilogue start with all loads landed; 512 ... 8192: below
 #ifndef IPDM_CONV_STAMPS
 #define IPDM_CONV_STAMPS 0          // `make stamps`: in-kernel s_memtime stamps of the phases (a stamped build changes what it measures)
 #endif
@@ -576,11 +580,11 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
             if (ch == nchunks - 2 && k + 1 < n_my) describe(k + 1);      // before the first loads of the next tile
             if (!(IPDM_WINO2_KO & 8)) issue_raw(ch2);          // raw(s + 2), consumed one iteration from now
         };
-        // The two waves of a SIMD (w and w + 4) take the chunk in OPPOSITE ORDER (IPDM_WINO3_STAGGER): waves 0-3 stage and transform
-        // chunk s + 1 first and multiply chunk s after, waves 4-7 multiply first -- the bf16 matrix pipe is a unit of its own, so one
-        // wave's MFMAs run under the other's activation / transform / split instructions (on the f32 MFMA, which shares the vector
-        // ALU, the same stagger bought nothing: conv_wino2.hip).  V(s + 1) goes into the stage chunk s - 1 read: free in either order.
-        const bool early = !IPDM_WINO3_STAGGER || swave < 4;
+        // Every wave stages and transforms chunk s + 1 first and multiplies chunk s after (V(s + 1) goes into the stage chunk s - 1 read).
+        // IPDM_WINO3_STAGGER 1 lets the two waves of a SIMD (w and w + 4) take the chunk in OPPOSITE order -- the bf16 matrix pipe is a unit
+        // of its own, so one wave's MFMAs run under the other's activation / transform / split instructions: x1.03 ... 1.05 -- and is NOT
+        // shipped: with any wave multiplying first, a process's first forward came out wrong on some boxes (the flag's comment above).
+        const bool early = IPDM_WINO3_STAGGER == 3 ? false : IPDM_WINO3_STAGGER == 4 ? swave >= 4 : (!IPDM_WINO3_STAGGER || swave < 4);      // (3: every wave multiplies first; 4: the halves swapped -- experiments)
         auto stage_all = [&]() __attribute__((always_inline)) {
             stage_next();
             if (!(IPDM_WINO2_KO & 2)) { read_patch(); transform_patch((s + 1) & 1); }
@@ -593,6 +597,8 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
 #pragma unroll
             for (int e = 0; e < ((IPDM_WINO3_DBG & 2048) ? 4 : 3); ++e) issue_u(e, 0);
         }
+        if (IPDM_WINO3_DBG & 32) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (debugging arm: every chunk starts with all loads landed)
+        if (IPDM_WINO3_DBG & 16) __syncthreads();                                                   // (debugging arm: a barrier at the top of every chunk ...)
         constexpr bool OLD = (IPDM_WINO3_DBG & 4096) != 0;      // (debugging arm: the FIRST version's structure -- stage at the start, patch read at e = 4, transform at the end)
         if (OLD) stage_next();
         else if (early) stage_all();
@@ -656,10 +662,20 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
 #pragma unroll
                     for (int t = 0; t < 3; ++t) bb[(e + 2) & 3][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + ((e + 2) * 3 + t) * 1024);
                 }
-            } else if (e + 1 < 8 && !(IPDM_WINO3_DBG & 512)) {
-                asm volatile("" ::"v"(bb[(e + 1) & 1][0]), "v"(bb[(e + 1) & 1][1]), "v"(bb[(e + 1) & 1][2]));
+            } else if (!(IPDM_WINO3_DBG & 512)) {
+                // (e = 7 too, although nothing is loaded behind the last position: the registers of position 6 are DEAD behind its MFMAs, and
+                //  without this use the allocator handed one of them to a temporary three instructions behind the chain's last MFMA -- a
+                //  `v_cndmask_b32 v196, 0, 1, s[74:75]` for the loop's own `ch + 1 < nchunks` -- in every instantiation.  Whether an MFMA that
+                //  waits in the matrix unit for its predecessor's accumulator has read its 128-bit B operand by then is not documented; the
+                //  write is kept out of that window on principle -- tools/check_mfma_war.py scans the compiled code for such writes, the build
+                //  is refused over one, IPDM_WINO3_DBG & 16384 brings this one back.  Closing it did NOT cure the first-forward defect of the
+                //  multiply-first orders (8 of 24 fresh processes still wrong: profiles/r06l_fix.log).)
+                if (e + 1 < 8 || !(IPDM_WINO3_DBG & 16384))
+                    asm volatile("" ::"v"(bb[(e + 1) & 1][0]), "v"(bb[(e + 1) & 1][1]), "v"(bb[(e + 1) & 1][2]));
+                if (e + 1 < 8) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) bb[(e + 1) & 1][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + ((e + 1) * 3 + t) * 1024);
+                    for (int t = 0; t < 3; ++t) bb[(e + 1) & 1][t] = *reinterpret_cast<const f32x4 *>(stage + b_off_b + ((e + 1) * 3 + t) * 1024);
+                }
             }
             // ... and the U terms of position e + 3 (this chunk's, or the next chunk's e - 5) into ring slot (e - 1) & 3
             if (IPDM_WINO3_DBG & 2048) {      // (debugging arm: the FIRST version's order for the U terms -- position e + 4 IN PLACE right behind the MFMAs of e)
@@ -725,6 +741,8 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
         float *sb = xw;                                      // statistics staging: the wave's scratch is idle here
         const f32x2 sgn2 = {sgn, sgn};
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        if (IPDM_WINO3_DBG & 32) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (IPDM_WINO3_DBG & 16) __syncthreads();                                                   // (... and one in front of the epilogue)
         // ALL residual loads of the tile are issued together, ahead of the transform
         f32x4 rv[8];
 #pragma unroll
@@ -851,10 +869,16 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
 
 namespace ipdm {
 
-// The layers conv_wino2 takes whole (no K split inside this kernel), when the option asks for the bf16 x 3 evaluation.
+// The layers of conv_wino2's SHAPE that are not K-split, when the option asks for the bf16 x 3 evaluation.  A rule of the layer
+// alone: this kernel's bits differ from the float32 Winograd kernels' (which are bit-identical to each other, so THEIR choice may
+// look at the batch), and a slice's result must not depend on the batch it was sharded into -- so, unlike conv_wino2_eligible,
+// no tile-count threshold here: under the option a lone slice runs these layers on 128-cout tiles too (slower for a lone slice
+// on the 64-tile levels; identical bits at every batch size: tests/test_gpu_parity.py::test_wino3_batch_is_its_slices).
 bool conv_wino3_eligible(const ConvArgs &a)
 {
-    return opt(OPT_CONV_BF16X3) > 0 && a.ksplit <= 1 && conv_wino2_eligible(a);
+    if (opt(OPT_CONV_BF16X3) <= 0 || opt(OPT_WINO_V1) || a.ksplit > 1) return false;
+    const int Ctot = a.C1 + a.C2;
+    return a.Cout % BN == 0 && Ctot % KC == 0 && (!a.C2 || a.C1 % KC == 0) && Ctot >= 2 * KC;
 }
 
 // `prepared`: as for conv2d_wino2_launch (a.w = the Winograd-domain weights: the f32 image, followed by the bf16 x 3 one)

@@ -406,6 +406,54 @@ struct ipdm_unet {
 
 namespace {
 
+#if IPDM_UNET_TRACE
+// IPDM_UNET_TRACE=1: the host waits for every convolution and sums its output; =2: a kernel behind every convolution adds the
+// output's words into a device slot (no host wait: the launches stay back to back), ipdm_trace_dump() prints the slots.
+__global__ void trace_sum_kernel(const unsigned *p, size_t n, unsigned long long *slot)
+{
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += (unsigned long long)p[i] * (i % 1021 + 1);
+    atomicAdd(slot, s);
+}
+std::vector<std::string> g_trace_desc;
+unsigned long long *g_trace_slots = nullptr;
+struct TraceRec { size_t off, n; int B, C, H, W; };
+std::vector<TraceRec> g_trace_rec;
+char *g_trace_pool = nullptr;
+size_t g_trace_used = 0;
+const size_t g_trace_pool_bytes = (size_t)48 << 30;
+void trace_conv(const ConvArgs &a, size_t n, hipStream_t st)
+{
+    char desc[256];
+    snprintf(desc, sizeof(desc), "code %2d  %3d+%-3d -> %3d @%4dx%-4d s%d act %d res %d planar %d stats %d", conv_kernel_code(a), a.C1, a.C2, a.Cout, a.Ho, a.Wo,
+             a.stride, a.act, a.res ? 1 : 0, a.x1_planar, a.stats ? a.stats_rows : 0);
+#if IPDM_UNET_TRACE == 1
+    std::vector<unsigned> h(n);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), a.out, n * 4, hipMemcpyDeviceToHost);
+    unsigned long long sum = 0;
+    for (size_t i = 0; i < n; ++i) sum += (unsigned long long)h[i] * (i % 1021 + 1);
+    fprintf(stderr, "TRACE %4zu %s  %016llx\n", g_trace_desc.size(), desc, sum);
+    g_trace_desc.push_back(desc);
+#elif IPDM_UNET_TRACE == 3
+    // a device copy of every convolution's output (one pool, carved up front: no allocation between the launches), compared by ipdm_trace_dump()
+    if (!g_trace_pool) { (void)hipMalloc((void **)&g_trace_pool, g_trace_pool_bytes); }
+    if (g_trace_used + n * 4 <= g_trace_pool_bytes) {
+        (void)hipMemcpyAsync(g_trace_pool + g_trace_used, a.out, n * 4, hipMemcpyDeviceToDevice, st);
+        g_trace_rec.push_back({g_trace_used, n, a.B, a.Cout, a.Ho, a.Wo});
+        g_trace_used += (n * 4 + 255) / 256 * 256;
+        g_trace_desc.push_back(desc);
+    }
+#else
+    if (!g_trace_slots) { (void)hipMalloc((void **)&g_trace_slots, 8192 * 8); (void)hipMemset(g_trace_slots, 0, 8192 * 8); }
+    if (g_trace_desc.size() < 8192) {
+        hipLaunchKernelGGL(trace_sum_kernel, dim3(512), dim3(256), 0, st, (const unsigned *)a.out, n, g_trace_slots + g_trace_desc.size());
+        g_trace_desc.push_back(desc);
+    }
+#endif
+}
+#endif
+
 int upload(ipdm_unet *net, const float *host, size_t n, float **out)
 {
     float *d = nullptr;
@@ -736,6 +784,9 @@ struct Fwd {
         a.out = ext_out ? ext_out : wptr(o);
         a.tiles_x = a.tiles_y = a.co_tiles = 0;
         rc = conv2d_launch(a, net->st);
+#if IPDM_UNET_TRACE      // diagnostic build (tools/build_variants.sh unet.hip trace:-DIPDM_UNET_TRACE=1): a checksum of every convolution's output
+        if (!rc) trace_conv(a, (size_t)net->B * cp.cout * Ho * Wo, net->st);
+#endif
         return o;
     }
 
@@ -1466,3 +1517,64 @@ extern "C" int ipdm_bench_attention(int32_t B, int32_t heads, int32_t d, int32_t
     (void)hipFree(d_qkv); (void)hipFree(d_out); (void)hipFree(d_scr); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
 }
+
+#if IPDM_UNET_TRACE == 2
+extern "C" void ipdm_trace_dump(void)
+{
+    std::vector<unsigned long long> h(g_trace_desc.size());
+    (void)hipDeviceSynchronize();
+    if (!h.empty()) (void)hipMemcpy(h.data(), g_trace_slots, h.size() * 8, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < h.size(); ++i) fprintf(stderr, "TRACE %4zu %s  %016llx\n", i, g_trace_desc[i].c_str(), h[i]);
+    g_trace_desc.clear();
+    if (g_trace_slots) (void)hipMemset(g_trace_slots, 0, 8192 * 8);
+}
+#endif
+
+#if IPDM_UNET_TRACE == 3
+// after the SECOND forward: the first convolution whose output differs between the two forwards, and where
+extern "C" void ipdm_trace_dump(void)
+{
+    static size_t first_count = 0;
+    (void)hipDeviceSynchronize();
+    if (!first_count) { first_count = g_trace_rec.size(); return; }
+    if (g_trace_rec.size() != 2 * first_count) { fprintf(stderr, "TRACE3 %zu records after the second forward, %zu after the first (pool %zu of %zu bytes)\n", g_trace_rec.size(), first_count, g_trace_used, g_trace_pool_bytes); return; }
+    for (size_t i = 0; i < first_count; ++i) {
+        const TraceRec &r1 = g_trace_rec[i], &r2 = g_trace_rec[first_count + i];
+        std::vector<float> h1(r1.n), h2(r2.n);
+        (void)hipMemcpy(h1.data(), g_trace_pool + r1.off, r1.n * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h2.data(), g_trace_pool + r2.off, r2.n * 4, hipMemcpyDeviceToHost);
+        if (!memcmp(h1.data(), h2.data(), r1.n * 4)) continue;
+        size_t bad = 0;
+        std::map<long, int> by_tile;      // (n, cout tile of 128, tile row of 4, tile column of 32) -> differing elements
+        fprintf(stderr, "TRACE3 first differing convolution #%zu: %s\n", i, g_trace_desc[i].c_str());
+        for (size_t j = 0; j < r1.n; ++j) {
+            if (!memcmp(&h1[j], &h2[j], 4)) continue;
+            const int x = (int)(j % r1.W), y = (int)(j / r1.W % r1.H), c = (int)(j / ((size_t)r1.W * r1.H) % r1.C), n = (int)(j / ((size_t)r1.W * r1.H * r1.C));
+            if (bad < 8) fprintf(stderr, "TRACE3   n %d cout %3d y %3d x %3d   first %.9g   second %.9g\n", n, c, y, x, h1[j], h2[j]);
+            by_tile[(((long)n * 64 + c / 128) * 4096 + y / 4) * 4096 + x / 32]++;
+            ++bad;
+        }
+        {
+            std::map<int, int> ys, cs, xs;
+            for (size_t j = 0; j < r1.n; ++j) {
+                if (!memcmp(&h1[j], &h2[j], 4)) continue;
+                xs[(int)(j % r1.W)]++; ys[(int)(j / r1.W % r1.H)]++; cs[(int)(j / ((size_t)r1.W * r1.H) % r1.C)]++;
+            }
+            for (auto *m : {&ys, &cs, &xs}) {
+                fprintf(stderr, "TRACE3   %s:", m == &ys ? "rows y" : m == &cs ? "couts" : "columns x");
+                for (auto &kv : *m) fprintf(stderr, " %d(%d)", kv.first, kv.second);
+                fprintf(stderr, "\n");
+            }
+        }
+        fprintf(stderr, "TRACE3 %zu of %zu elements differ, in %zu (sample, cout tile, 4-row, 32-column) tiles:\n", bad, r1.n, by_tile.size());
+        int shown = 0;
+        for (auto &kv : by_tile) {
+            if (shown++ >= 24) break;
+            fprintf(stderr, "TRACE3   sample %ld cout tile %ld rows %ld.. columns %ld..: %d elements\n", kv.first / 4096 / 4096 / 64, kv.first / 4096 / 4096 % 64,
+                    kv.first / 4096 % 4096 * 4, kv.first % 4096 * 32, kv.second);
+        }
+        return;
+    }
+    fprintf(stderr, "TRACE3 the two forwards agree in every convolution\n");
+}
+#endif

@@ -835,11 +835,45 @@ def test_wino3_run_to_run_determinism():
     for case in [(2, 128, 0, 37, 145, 128, 2, True), (1, 128, 0, 130, 250, 128, 2, True), (2, 128, 0, 36, 144, 128, 0, False),
                  (2, 64, 64, 45, 95, 128, 1, True), (8, 128, 0, 128, 128, 128, 2, True), (3, 128, 16, 40, 104, 128, 2, True)]:
         with _lib.option("conv_bf16x3", 1):
-            assert _lib.lib().ipdm_conv_kernel_code(case[0], case[5], case[1] + case[2], 3, 1, case[3], case[4]) in (12, 1), case
+            assert _lib.lib().ipdm_conv_kernel_code(case[0], case[5], case[1] + case[2], 3, 1, case[3], case[4]) == 12, case
             bad, first, _ = _conv3x3_repeats(*case, reps=60)
         _, ref, _ = _conv3x3_repeats(*case, reps=0)
         assert bad == 0, (bad, case)
         assert (first - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), case
+
+
+def test_wino3_batch_is_its_slices():
+    """Under option conv_bf16x3 the kernel choice is a rule of the layer ALONE (conv_wino3's bits are not the float32 Winograd
+    kernels', so -- unlike the choice between those two -- it must not look at the batch): a batch's result is, bit for bit, its
+    slices' results run alone, also on the levels where the default rule gives a lone slice the 64-cout kernel (64 tiles per
+    sample at 256 -> 256 @64x64).  The first version of the option broke this: the whole suite run under IPDM_CONV_BF16X3=1
+    (profiles/r06j_suite_bf16x3.txt) found a B = 2 batch 2.9e-6 away from its slices."""
+    from ipdm_pytorch_amd import _lib
+    code = _lib.lib().ipdm_conv_kernel_code
+    for case in [(8, 256, 0, 64, 64, 256, 2, True), (8, 128, 16, 40, 104, 128, 2, True), (3, 128, 128, 125, 57, 128, 1, False)]:
+        B, C1, C2, H, W, Cout, act, res = case
+        Cin, seed = C1 + C2, 8900 + sum(case[:6])
+        assert code(1, Cout, Cin, 3, 1, H, W) == 1 and code(8, Cout, Cin, 3, 1, H, W) == 2, case     # (the default rule looks at the batch)
+        x1 = torch.from_numpy(synth.hash_normal((B, C1, H, W), seed)).to(DEV)
+        x2 = torch.from_numpy(synth.hash_normal((B, C2, H, W), seed + 1)).to(DEV) if C2 else None
+        rd = torch.from_numpy(synth.hash_normal((B, Cout, H, W), seed + 6)).to(DEV) if res else None
+        wn, bn, gn_, ben = (np.ascontiguousarray(t, dtype=np.float32) for t in (
+            synth.hash_normal((Cout, Cin, 3, 3), seed + 2) / np.sqrt(Cin * 9), synth.hash_normal((Cout,), seed + 3),
+            synth.hash_uniform((Cin,), seed + 4) + 0.5, synth.hash_normal((Cin,), seed + 5) * 0.2))
+
+        def run(lo, hi):
+            out = torch.full((hi - lo, Cout, H, W), float("nan"), device=DEV)
+            a, b, r = x1[lo:hi].contiguous(), (x2[lo:hi].contiguous() if C2 else None), (rd[lo:hi].contiguous() if res else None)
+            _lib.call("ipdm_op_conv2d", _lib.ptr(a), C1, _lib.ptr(b), C2, hi - lo, H, W, H, W, _lib.ptr(wn), _lib.ptr(bn), Cout, 3, 1,
+                      act, ou.gn_groups(Cin), _lib.ptr(gn_), _lib.ptr(ben), _lib.ptr(r), _lib.ptr(out), _lib.current_stream())
+            return out
+        with _lib.option("conv_bf16x3", 1):
+            assert code(1, Cout, Cin, 3, 1, H, W) == 12 and code(B, Cout, Cin, 3, 1, H, W) == 12, case
+            whole = run(0, B)
+            for i in range(B):
+                assert torch.equal(run(i, i + 1)[0], whole[i]), (case, i)
+        ref = run(0, B)                                                                                 # (conv_wino2)
+        assert not torch.equal(ref, whole) and (ref - whole).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), case
 
 
 PW_CASES = [
@@ -2088,6 +2122,54 @@ def test_full_size_pipeline_bf16x3_alt_mode(oracle_pool):
     assert all(not np.array_equal(r[4], r[0]) for r in runs)          # (the option did route layers to the other kernel)
     arb = [(r[4], w, oracle_pool.result(r[2])) for r, w in zip(runs, wants) if r[2] is not None]
     _arbiter_ratios("full size conv_bf16x3", [a[0] for a in arb], [a[1] for a in arb], [a[2] for a in arb])
+
+
+def test_bf16x3_first_forward_of_a_process():
+    """The defect that kept conv_bf16x3's faster wave order out of the library (conv_wino3.hip, IPDM_WINO3_STAGGER; NOTEBOOK.md round 6): with any
+    wave multiplying before it staged, the FIRST forward of a process was wrong (1e-2 relative in one workgroup tile of one convolution) in 30 - 50 %
+    of fresh processes on two of the boxes seen -- later forwards, blocking launches and every in-process repetition test were clean, so nothing in
+    the suite saw it until the whole suite ran under the option.  Four fresh processes of the shipped order (and one of the float32 kernels):
+    every forward bit-equal to the process's fourth."""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_first_forward_child.py")
+    for on in (1, 1, 1, 1, 0):
+        r = subprocess.run([sys.executable, child, str(on)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (on, r.returncode, r.stdout[-300:], r.stderr[-600:])
+
+
+def test_bf16x3_pipeline_batch_is_its_slices():
+    """Option conv_bf16x3 through the whole path at full size (production UNets, 2000x912 sinograms, adaptive guidance, FBP,
+    sharpen, image domain, ultra pass; two steps per stage): a batch of THREE slices equals, bit for bit, each of its slices
+    sampled alone (global slice id kept) -- the property sharding across ranks rests on, which the default path has because its
+    batch-dependent kernel choices are between bit-identical kernels, and which the option keeps by choosing conv_wino3 by the
+    layer alone."""
+    from ipdm_pytorch_amd import _lib
+    from ipdm_pytorch_amd.config import default_cfg, cfg_load, mayo_test_options
+    from ipdm_pytorch_amd.denoiser import progressive_domain_denoiser
+    opt = default_cfg([])
+    cfg_load(mayo_test_options(), opt.__dict__)
+    cfg_load(dict(t_start_proj=[2, 2], t_start_img=[2], ultra_img_denoise=True, device=DEV), opt.__dict__)
+    sinos = np.stack([synth.low_dose(synth.fan_sinogram(synth.ellipse_phantom(p)), seed=p) for p in (0, 1, 2)])
+    with _lib.option("conv_bf16x3", 1):
+        den = progressive_domain_denoiser(opt, seed=321)
+        den.data_sample_load(ldproj=torch.from_numpy(sinos)[:, None])
+        whole = den.progressive_denoiser(sharpen_num=70).cpu().numpy()
+        del den
+        for b in (0, 2):
+            one = progressive_domain_denoiser(opt, seed=321, slice_id0=b)
+            one.data_sample_load(ldproj=torch.from_numpy(sinos[b:b + 1])[:, None])
+            alone = one.progressive_denoiser(sharpen_num=70).cpu().numpy()
+            del one
+            assert np.array_equal(alone, whole[b:b + 1]), (b, float(np.abs(alone - whole[b:b + 1]).max()))
+    den = progressive_domain_denoiser(opt, seed=321)
+    den.data_sample_load(ldproj=torch.from_numpy(sinos)[:, None])
+    ref = den.progressive_denoiser(sharpen_num=70).cpu().numpy()
+    del den
+    torch.cuda.empty_cache()
+    d = float(np.abs(ref - whole).max())
+    print("conv_bf16x3, B = 3 full size: batch == slices (bitwise); against the default path max-abs %.2e" % d)
+    assert 0.0 < d <= FULL_SIZE_MAX_REL * max(1.0, float(np.abs(ref).max()))
 
 
 @pytest.mark.oracle_join
