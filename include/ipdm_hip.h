@@ -297,7 +297,7 @@ int32_t ipdm_conv_layout_code(int32_t Cout, int32_t ksize, int32_t stride);
  *   9 = conv_wino2 with K slices + combine pass (the layers with too few tiles per sample)
  *   10 = conv_pw (wide 1x1 layers: the barrier-free pointwise kernel)
  *   11 = conv_wup2 (an Upsample's parity form in the Winograd F(2x2,2x2) domain; never for this plain shape)
- *   12 = conv_wino3 (conv_wino2's layers under the opt-in option conv_bf16x3: products on the bf16 matrix pipe, 3-way split)
+ *   12 = conv_wino3 (under the opt-in option conv_bf16x3 the layers of conv_wino2's SHAPE, whatever the batch: products on the bf16 matrix pipe, 3-way split)
  *   -1 = bad argument.
  * Test aid (replaces nothing in the reference): a parity test asserts the kernel it believes it covers. */
 int32_t ipdm_conv_kernel_code(int32_t B, int32_t Cout, int32_t Cin, int32_t ksize, int32_t stride, int32_t H, int32_t W);

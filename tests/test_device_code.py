@@ -57,3 +57,26 @@ def test_the_scanner_treats_both_operands_of_a_swap_as_written():
     assert len(ch.check({"k": [store, swap, end]}, "x.o", notes)) == 1
     notes = []
     assert ch.check({"k": [store, (8, "s_nop", ["0"]), (12, "v_permlane16_swap_b32", ["v9", "v3"]), end]}, "x.o", notes) == [] and len(notes) == 1
+
+
+WAR = os.path.join(ROOT, "tools", "check_mfma_war.py")
+
+
+def test_no_early_write_of_an_mfma_source_operand_in_the_built_libraries(tmp_path):
+    """tools/check_mfma_war.py (round 6): no VALU write of a 128-bit MFMA source operand in the window behind the MFMA, in any kernel of the
+    built libraries; and the positive control -- conv_wino3.hip with the pin of position 6's dead B operand taken out again
+    (IPDM_WINO3_DBG & 16384) is flagged in all four instantiations: `v_cndmask_b32_e64 v196, 0, 1, ..` three slots behind the last MFMA of
+    the position's accumulate chain."""
+    objs = sorted(glob.glob(os.path.join(CSRC, "*.o")))
+    assert len(objs) >= 14, "csrc/*.o missing: run __graft_entry__.build()"
+    r = subprocess.run([sys.executable, WAR] + objs, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 VALU write(s)" in r.stdout, r.stdout[-2000:]
+    obj = str(tmp_path / "wino3_hole.o")
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-function", "-DIPDM_WINO3_DBG=16384", "-I" + CSRC, "-c",
+                    os.path.join(CSRC, "conv_wino3.hip"), "-o", obj], check=True, capture_output=True, timeout=900)
+    r = subprocess.run([sys.executable, WAR, obj], capture_output=True, text=True, timeout=600)
+    flagged = [ln for ln in r.stdout.splitlines() if ln.startswith("MFMA SOURCE WAR")]
+    assert r.returncode == 1 and len(flagged) >= 4, r.stdout[-2000:]
+    assert all("v_mfma_f32_32x32x16_bf16" in ln and "v_cndmask_b32" in ln for ln in flagged), r.stdout[-2000:]
+    assert len({ln.split("conv_wino3_kernelIL")[1][:6] for ln in flagged}) == 4, flagged      # every instantiation
+
