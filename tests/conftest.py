@@ -14,6 +14,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "oracle_submit: device half of a heavy parity test; hands its CPU replays to the oracle pool (collected first)")
     config.addinivalue_line("markers", "oracle_join: verdict half: joins the replays of its oracle_submit twin (collected last)")
+    config.addinivalue_line("markers", "run_last: behind everything else (a check of an opt-in mode's unexplained defect: under -x a failure there must not cost other tests)")
 
 
 # Collection order of the GPU suite (round 6; round 5's order lost sixteen tests to the driver's 1200 s limit): the device halves
@@ -24,7 +25,7 @@ _FILE_ORDER = {"test_gpu_pipeline.py": 0, "test_gpu_parity.py": 1}
 
 def pytest_collection_modifyitems(session, config, items):
     def key(it):
-        phase = 0 if it.get_closest_marker("oracle_submit") else 2 if it.get_closest_marker("oracle_join") else 1
+        phase = 0 if it.get_closest_marker("oracle_submit") else 2 if it.get_closest_marker("oracle_join") else 3 if it.get_closest_marker("run_last") else 1
         return (phase, _FILE_ORDER.get(os.path.basename(str(it.fspath)), 2) if it.get_closest_marker("gpu") else -1)
     items.sort(key=key)          # stable: the order inside a file is kept
 

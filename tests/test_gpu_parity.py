@@ -2124,12 +2124,14 @@ def test_full_size_pipeline_bf16x3_alt_mode(oracle_pool):
     _arbiter_ratios("full size conv_bf16x3", [a[0] for a in arb], [a[1] for a in arb], [a[2] for a in arb])
 
 
+@pytest.mark.run_last
 def test_bf16x3_first_forward_of_a_process():
     """The defect that kept conv_bf16x3's faster wave order out of the library (conv_wino3.hip, IPDM_WINO3_STAGGER; NOTEBOOK.md round 6): with any
     wave multiplying before it staged, the FIRST forward of a process was wrong (1e-2 relative in one workgroup tile of one convolution) in 30 - 50 %
     of fresh processes on two of the boxes seen -- later forwards, blocking launches and every in-process repetition test were clean, so nothing in
     the suite saw it until the whole suite ran under the option.  Four fresh processes of the shipped order (and one of the float32 kernels):
-    every forward bit-equal to the process's fourth."""
+    every forward bit-equal to the process's fourth.  Collected LAST (marker run_last): the cause is not identified, the shipped order is
+    clean by observation only (0 of 48 fresh processes) -- should it fail on some box, `pytest -x` has run everything else by then."""
     import subprocess
     import sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_first_forward_child.py")

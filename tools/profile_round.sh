@@ -2,12 +2,14 @@
 # Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>_*  (copy the summaries you want judged into profiles/)
 # Counters are collected in their own passes (--pmc with --kernel-trace only), never with --stats.
-# (the traced bench runs two warm-up and two timed steps: its line then carries `clock`, the shader clock the box held -- the boxes of
-#  the pool differ by up to 6 % --, and the kernel statistics average over five steps: 2 + 2 + the untimed profiling step)
+# (the traced bench runs ONE warm-up and three timed steps: with two or more warm-up steps bench.py samples the shader clock under the last of
+#  them with one extra wave on a stream of its own -- that wave keeps one SIMD from taking two of conv_wino2's 256-register waves, so the kernel's
+#  256 workgroups run on 255 CUs for that untimed step (x1.4 per launch) and the trace's average over ALL steps reads 0.465 ms where the timed
+#  steps' events read 0.428: profiles/r06p_*.  The kernel statistics average over five steps: 1 + 3 + the untimed profiling step.)
 TAG=${1:-r02}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-alt --no-extra-legs > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-extra-legs > $OUT/${TAG}_trace_bench.json 2> $OUT/${TAG}_trace.err
 python3 tools/rocpd_summary.py $(find $OUT/${TAG}_trace -name "*.db" | head -1) $OUT/${TAG}_bench_b8
 # HBM traffic of every kernel (per-launch averages): two separate counter passes.  A counter pass serialises every
 # dispatch (a full step of 23k launches takes > 25 minutes), so the passes run a step with the same 3 : 2 mix of proj and
@@ -21,6 +23,7 @@ cp profiles/${TAG}_traffic.json profiles/${TAG}_hbm_by_kernel.csv $OUT/
 fi
 # matrix-pipe utilisation of two common shapes of the dominant kernel (conv_wino2: 128->128 @512x512, 256->256 @128x128)
 # ... and of the F(2x2,2x2) Upsample kernel (conv_wup2: 128 channels, source 228x500; act 512 = the micro-benchmark's Upsample mode)
+[ -n "$SKIP_PMC" ] && exit 0
 for shape in "8 128 0 512 512 128 3 1 2 1" "8 256 0 128 128 256 3 1 2 1" "8 128 0 228 500 128 3 1 512 0"; do
   name=$(echo $shape | tr ' ' '_')
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU --kernel-trace -d $OUT/${TAG}_pmc_sq_$name -o c -- python3 tools/one_conv.py $shape > /dev/null 2>&1
