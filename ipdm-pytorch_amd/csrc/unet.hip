@@ -406,6 +406,9 @@ struct ipdm_unet {
 
 namespace {
 
+#ifndef IPDM_UNET_TRACE
+#define IPDM_UNET_TRACE 0           // diagnostic builds only (tools/build_variants.sh unet.hip trace:-DIPDM_UNET_TRACE=1 ...; loaded through IPDM_LIB_PATH)
+#endif
 #if IPDM_UNET_TRACE
 // IPDM_UNET_TRACE=1: the host waits for every convolution and sums its output; =2: a kernel behind every convolution adds the
 // output's words into a device slot (no host wait: the launches stay back to back), ipdm_trace_dump() prints the slots.
