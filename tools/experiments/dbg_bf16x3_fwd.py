@@ -27,6 +27,19 @@ elif warm == "alloc":        # memory the process has touched before: 12 GiB fil
     blocks = [torch.full((256 << 20,), 1.0, device=DEV) for _ in range(12)]      # input and the outputs of the first forward come from these blocks)
     torch.cuda.synchronize()
     del blocks
+elif warm == "scratch":      # the kernels of this library with the LARGEST private-segment (scratch) need first -- conv_ws: 256 ... 280 bytes per lane --, the host
+    from oracle import unet as ou                                     # waiting behind each: the queue's scratch has its final size before the forward starts
+    for (C, Co, H, W, ks, st) in [(16, 128, 64, 64, 3, 1), (128, 128, 16, 16, 3, 1), (128, 128, 64, 64, 3, 2), (128, 256, 64, 64, 1, 1), (16, 128, 250, 114, 3, 1)]:
+        xw = torch.from_numpy(synth.hash_normal((1, C, H, W), 3)).to(DEV)
+        Ho, Wo = (H + 2 * (ks // 2) - ks) // st + 1, (W + 2 * (ks // 2) - ks) // st + 1
+        ow = torch.empty((1, Co, Ho, Wo), device=DEV)
+        wn, bn, gn_, ben = (np.ascontiguousarray(t, dtype=np.float32) for t in (
+            synth.hash_normal((Co, C, ks, ks), 5) / np.sqrt(C * ks * ks), synth.hash_normal((Co,), 6), synth.hash_uniform((C,), 7) + 0.5, synth.hash_normal((C,), 8) * 0.2))
+        with _lib.option("conv_no_pw", 1):
+            print("scratch warm-up: code", _lib.lib().ipdm_conv_kernel_code(1, Co, C, ks, st, H, W), (C, Co, H, W, ks, st), flush=True)
+            _lib.call("ipdm_op_conv2d", _lib.ptr(xw), C, None, 0, 1, H, W, H, W, _lib.ptr(wn), _lib.ptr(bn), Co, ks, st,
+                      0, ou.gn_groups(C), _lib.ptr(gn_), _lib.ptr(ben), None, _lib.ptr(ow), _lib.current_stream())
+        torch.cuda.synchronize()
 elif warm == "ops":          # conv_wino3 alone first (both non-planar instantiations), the host waiting behind each launch
     from oracle import unet as ou
     for res in (True, False):
