@@ -65,7 +65,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
                                     //    (x1.03 ... 1.05 faster; 3: every wave multiplies first; 4: the halves swapped) -- with ANY wave in the multiply-first order
                                     //    the FIRST forward of a process came out wrong (one Winograd position of sixteen tiles of one workgroup tile, all couts,
                                     //    1e-2 relative) in 30 ... 50 % of fresh processes on two of the boxes seen, never in later forwards, never with blocking
-                                    //    launches, never in this order (0 of 16 + 30 processes): NOTEBOOK.md round 6, tools/experiments/dbg_bf16x3_fwd.py.  Cause not identified.
+                                    //    launches, never in this order (0 of 60 processes): NOTEBOOK.md round 6, tools/experiments/dbg_bf16x3_fwd.py.  Cause not identified.
 #endif
 #ifndef IPDM_WINO3_BBUF
 #define IPDM_WINO3_BBUF 2

@@ -2131,7 +2131,7 @@ def test_bf16x3_first_forward_of_a_process():
     of fresh processes on two of the boxes seen -- later forwards, blocking launches and every in-process repetition test were clean, so nothing in
     the suite saw it until the whole suite ran under the option.  Four fresh processes of the shipped order (and one of the float32 kernels):
     every forward bit-equal to the process's fourth.  Collected LAST (marker run_last): the cause is not identified, the shipped order is
-    clean by observation only (0 of 48 fresh processes) -- should it fail on some box, `pytest -x` has run everything else by then."""
+    clean by observation only (0 of 60 fresh processes) -- should it fail on some box, `pytest -x` has run everything else by then."""
     import subprocess
     import sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_first_forward_child.py")
