@@ -62,11 +62,22 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef IPDM_WINO3_STAGGER
 #define IPDM_WINO3_STAGGER 0        // 0 (shipped): every wave stages / transforms chunk s + 1 first and multiplies chunk s after.  1: waves 4-7 multiply first
-                                    //    (x1.03 ... 1.05 faster; 3: every wave multiplies first; 4: the halves swapped) -- with ANY wave in the multiply-first order
-                                    //    the FIRST forward of a process came out wrong (one Winograd position of sixteen tiles of one workgroup tile, all couts,
-                                    //    1e-2 relative) in 30 ... 50 % of fresh processes on two of the boxes seen, never in later forwards, never with blocking
-                                    //    launches, never in this order (0 of 60 processes): NOTEBOOK.md round 6, tools/experiments/dbg_bf16x3_fwd.py.  Cause not identified.
+                                    //    (x1.03 ... 1.05 faster; 3: every wave multiplies first; 4: the halves swapped).  With ANY wave in the multiply-first order and
+                                    //    the input transform's packed add (IPDM_WINO3_PKFIX 0, below) the FIRST forward of a process came out wrong (one Winograd
+                                    //    position of sixteen tiles of one workgroup tile, all couts, 1e-2 relative) in 30 ... 50 % of fresh processes on three of the
+                                    //    boxes seen; never in later forwards, never with blocking launches, never in this order (0 of 60 processes).  The instruction
+                                    //    is identified and replaced (PKFIX 2: 0 of 10 in the multiply-first order); this order stays until that has more runs behind it.
+                                    //    NOTEBOOK.md round 6, tools/experiments/dbg_bf16x3_fwd.py, analyze_trace3.py.
 #endif
+#ifndef IPDM_WINO3_PKFIX
+#define IPDM_WINO3_PKFIX 2          // how columns j = 2, 3 of the input transform are formed (transform_patch).  0: conv_wino2's packed add
+#endif                              //    `v_pk_add_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]`, whose LOW result takes the HIGH half of b: the
+                                    //    instruction behind the first-forward defect (IPDM_WINO3_STAGGER above) -- in the wrong forwards the low result of ONE such
+                                    //    instruction is `a.lo + 0` instead of `a.lo - b.hi` in lanes 48-63 (tools/experiments/analyze_trace3.py recovers T2 to 1e-7 from
+                                    //    the two outputs: profiles/r06v_analysis.log).  1: the same with a destination that is not a source: still wrong (5 of 10 fresh
+                                    //    processes).  2 (shipped): two plain subtractions -- the same bits; multiply-first order with it: 0 of 10 beside 3/10 and 5/10
+                                    //    (profiles/r06w_pkfix.log).  Why the packed form fails there is not known (it needs the wave's own MFMAs in flight, a process's
+                                    //    first forward, asynchronous launches); conv_wino2.hip uses it in the stage-first order, where it has never been seen to fail.
 #ifndef IPDM_WINO3_BBUF
 #define IPDM_WINO3_BBUF 2
 #endif
@@ -443,7 +454,13 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
                 const int rs = row_slot(i);
                 f32x2 o01, o23;
                 asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(o01) : "v"(T[i][0]), "v"(T[i][1]));
+#if IPDM_WINO3_PKFIX == 1      // the destination may not be one of the sources
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=&v"(o23) : "v"(T[i][1]), "v"(T[i][0]));
+#elif IPDM_WINO3_PKFIX == 2    // two plain subtractions instead of the packed add that takes the HIGH half of its second source for its LOW result
+                o23 = f32x2{T[i][1][0] - T[i][0][1], T[i][0][1] - T[i][1][1]};
+#else
                 asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(o23) : "v"(T[i][1]), "v"(T[i][0]));
+#endif
                 o[rs * 4 + 0] = o01[0]; o[rs * 4 + 1] = o01[1]; o[rs * 4 + 2] = o23[0]; o[rs * 4 + 3] = o23[1];
             }
         } else {
@@ -583,7 +600,8 @@ __global__ void __launch_bounds__(512) conv_wino3_kernel(ConvArgs a, int ntiles)
         // Every wave stages and transforms chunk s + 1 first and multiplies chunk s after (V(s + 1) goes into the stage chunk s - 1 read).
         // IPDM_WINO3_STAGGER 1 lets the two waves of a SIMD (w and w + 4) take the chunk in OPPOSITE order -- the bf16 matrix pipe is a unit
         // of its own, so one wave's MFMAs run under the other's activation / transform / split instructions: x1.03 ... 1.05 -- and is NOT
-        // shipped: with any wave multiplying first, a process's first forward came out wrong on some boxes (the flag's comment above).
+        // shipped yet: with any wave multiplying first, a process's first forward came out wrong on some boxes through one packed add of the
+        // input transform (the flags' comments above; that instruction is gone from this kernel, the order waits for more runs).
         const bool early = IPDM_WINO3_STAGGER == 3 ? false : IPDM_WINO3_STAGGER == 4 ? swave >= 4 : (!IPDM_WINO3_STAGGER || swave < 4);      // (3: every wave multiplies first; 4: the halves swapped -- experiments)
         auto stage_all = [&]() __attribute__((always_inline)) {
             stage_next();

@@ -420,7 +420,7 @@ __global__ void trace_sum_kernel(const unsigned *p, size_t n, unsigned long long
 }
 std::vector<std::string> g_trace_desc;
 unsigned long long *g_trace_slots = nullptr;
-struct TraceRec { size_t off, n; int B, C, H, W; };
+struct TraceRec { size_t off, n; int B, C, H, W; size_t off_x1 = 0, off_sc = 0, off_sh = 0; int C1 = 0, code = 0; const float *w = nullptr; };
 std::vector<TraceRec> g_trace_rec;
 char *g_trace_pool = nullptr;
 size_t g_trace_used = 0;
@@ -443,8 +443,17 @@ void trace_conv(const ConvArgs &a, size_t n, hipStream_t st)
     if (!g_trace_pool) { (void)hipMalloc((void **)&g_trace_pool, g_trace_pool_bytes); }
     if (g_trace_used + n * 4 <= g_trace_pool_bytes) {
         (void)hipMemcpyAsync(g_trace_pool + g_trace_used, a.out, n * 4, hipMemcpyDeviceToDevice, st);
-        g_trace_rec.push_back({g_trace_used, n, a.B, a.Cout, a.Ho, a.Wo});
+        TraceRec rec{g_trace_used, n, a.B, a.Cout, a.Ho, a.Wo};
         g_trace_used += (n * 4 + 255) / 256 * 256;
+        rec.code = conv_kernel_code(a);
+        const size_t nx = (size_t)a.B * a.C1 * a.Hs * a.Ws * 4, ng = (size_t)a.B * (a.C1 + a.C2) * 4;
+        if (rec.code == 12 && a.C2 == 0 && a.act && g_trace_used + nx + 2 * ng + 1024 <= g_trace_pool_bytes) {      // the inputs too: ipdm_trace_dump() writes them out for the first wrong one
+            rec.C1 = a.C1; rec.w = a.w_wino;
+            rec.off_x1 = g_trace_used; (void)hipMemcpyAsync(g_trace_pool + g_trace_used, a.x1, nx, hipMemcpyDeviceToDevice, st); g_trace_used += (nx + 255) / 256 * 256;
+            rec.off_sc = g_trace_used; (void)hipMemcpyAsync(g_trace_pool + g_trace_used, a.gn_scale, ng, hipMemcpyDeviceToDevice, st); g_trace_used += (ng + 255) / 256 * 256;
+            rec.off_sh = g_trace_used; (void)hipMemcpyAsync(g_trace_pool + g_trace_used, a.gn_shift, ng, hipMemcpyDeviceToDevice, st); g_trace_used += (ng + 255) / 256 * 256;
+        }
+        g_trace_rec.push_back(rec);
         g_trace_desc.push_back(desc);
     }
 #else
@@ -1550,6 +1559,19 @@ extern "C" void ipdm_trace_dump(void)
         size_t bad = 0;
         std::map<long, int> by_tile;      // (n, cout tile of 128, tile row of 4, tile column of 32) -> differing elements
         fprintf(stderr, "TRACE3 first differing convolution #%zu: %s\n", i, g_trace_desc[i].c_str());
+        if (r1.C1 && getenv("IPDM_TRACE_DUMP_DIR")) {      // both outputs, the input, the GroupNorm table and the Winograd-domain weights: tools/experiments/analyze_trace3.py
+            const std::string dir = getenv("IPDM_TRACE_DUMP_DIR");
+            auto put = [&](const char *name, const void *host, size_t bytes) { FILE *f = fopen((dir + "/" + name).c_str(), "wb"); if (f) { fwrite(host, 1, bytes, f); fclose(f); } };
+            put("out1.bin", h1.data(), r1.n * 4); put("out2.bin", h2.data(), r2.n * 4);
+            std::vector<float> t((size_t)r1.B * r1.C1 * r1.H * r1.W);
+            (void)hipMemcpy(t.data(), g_trace_pool + r1.off_x1, t.size() * 4, hipMemcpyDeviceToHost); put("x1.bin", t.data(), t.size() * 4);
+            t.resize((size_t)r1.B * r1.C1);
+            (void)hipMemcpy(t.data(), g_trace_pool + r1.off_sc, t.size() * 4, hipMemcpyDeviceToHost); put("sc.bin", t.data(), t.size() * 4);
+            (void)hipMemcpy(t.data(), g_trace_pool + r1.off_sh, t.size() * 4, hipMemcpyDeviceToHost); put("sh.bin", t.data(), t.size() * 4);
+            t.resize((size_t)(r1.C1 / 8) * (r1.C / 64) * 8192);
+            (void)hipMemcpy(t.data(), r1.w, t.size() * 4, hipMemcpyDeviceToHost); put("u.bin", t.data(), t.size() * 4);
+            char meta[128]; snprintf(meta, sizeof(meta), "%d %d %d %d %d %zu\n", r1.B, r1.C1, r1.C, r1.H, r1.W, i); put("meta.txt", meta, strlen(meta));
+        }
         for (size_t j = 0; j < r1.n; ++j) {
             if (!memcmp(&h1[j], &h2[j], 4)) continue;
             const int x = (int)(j % r1.W), y = (int)(j / r1.W % r1.H), c = (int)(j / ((size_t)r1.W * r1.H) % r1.C), n = (int)(j / ((size_t)r1.W * r1.H * r1.C));

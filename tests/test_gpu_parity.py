@@ -2130,8 +2130,10 @@ def test_bf16x3_first_forward_of_a_process():
     wave multiplying before it staged, the FIRST forward of a process was wrong (1e-2 relative in one workgroup tile of one convolution) in 30 - 50 %
     of fresh processes on two of the boxes seen -- later forwards, blocking launches and every in-process repetition test were clean, so nothing in
     the suite saw it until the whole suite ran under the option.  Four fresh processes of the shipped order (and one of the float32 kernels):
-    every forward bit-equal to the process's fourth.  Collected LAST (marker run_last): the cause is not identified, the shipped order is
-    clean by observation only (0 of 60 fresh processes) -- should it fail on some box, `pytest -x` has run everything else by then."""
+    every forward bit-equal to the process's fourth.  The instruction behind it is identified (a packed add of the input transform whose low
+    result takes the high half of a source: `a.lo + 0` instead of `a.lo - b.hi` in lanes 48-63) and replaced, and the shipped order never
+    showed it (0 of 60 fresh processes); WHY that instruction fails there is not known, so the check stays -- collected LAST (marker
+    run_last): should it fail on some box, `pytest -x` has run everything else by then."""
     import subprocess
     import sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_first_forward_child.py")
