@@ -66,7 +66,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
                                     //    the input transform's packed add (IPDM_WINO3_PKFIX 0, below) the FIRST forward of a process came out wrong (one Winograd
                                     //    position of sixteen tiles of one workgroup tile, all couts, 1e-2 relative) in 30 ... 50 % of fresh processes on three of the
                                     //    boxes seen; never in later forwards, never with blocking launches, never in this order (0 of 60 processes).  The instruction
-                                    //    is identified and replaced (PKFIX 2: 0 of 10 in the multiply-first order); this order stays until that has more runs behind it.
+                                    //    is identified and replaced (PKFIX 2: 0 of 32 in the multiply-first order); this order stays for this round (every gate was run on it).
                                     //    NOTEBOOK.md round 6, tools/experiments/dbg_bf16x3_fwd.py, analyze_trace3.py.
 #endif
 #ifndef IPDM_WINO3_PKFIX
@@ -75,8 +75,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
                                     //    instruction behind the first-forward defect (IPDM_WINO3_STAGGER above) -- in the wrong forwards the low result of ONE such
                                     //    instruction is `a.lo + 0` instead of `a.lo - b.hi` in lanes 48-63 (tools/experiments/analyze_trace3.py recovers T2 to 1e-7 from
                                     //    the two outputs: profiles/r06v_analysis.log).  1: the same with a destination that is not a source: still wrong (5 of 10 fresh
-                                    //    processes).  2 (shipped): two plain subtractions -- the same bits; multiply-first order with it: 0 of 10 beside 3/10 and 5/10
-                                    //    (profiles/r06w_pkfix.log).  Why the packed form fails there is not known (it needs the wave's own MFMAs in flight, a process's
+                                    //    processes).  2 (shipped): two plain subtractions -- the same bits; multiply-first order with it: 0 of 32 beside 3/10 and 5/10
+                                    //    (profiles/r06w_pkfix.log, r06y_stag_sub.log).  Why the packed form fails there is not known (it needs the wave's own MFMAs in flight, a process's
                                     //    first forward, asynchronous launches); conv_wino2.hip uses it in the stage-first order, where it has never been seen to fail.
 #ifndef IPDM_WINO3_BBUF
 #define IPDM_WINO3_BBUF 2
